@@ -1,0 +1,158 @@
+"""Generate tests/golden/*.npz.  Runs in the BUILD CONTAINER only (needs /root/reference).
+
+Two kinds of fixture:
+
+1. ``ref_blocks_<variant>.npz`` - outputs of the reference's OWN classes
+   (model/decoder.py, model/lraspp.py, model/deep_guided_filter.py,
+   model/fast_guided_filter.py, imported by file path; they only need torch) on
+   seeded inputs and seeded weights.  They pin oracle/rvm_oracle.py.
+   The encoders (model/mobilenetv3.py, model/resnet.py) and model/model.py import
+   torchvision, which is absent -> ordinary ModuleNotFoundError -> not run;
+   those parts of the oracle stay "parity unpinned" (see rvm_oracle.py header).
+
+2. ``e2e_<variant>_<tag>.npz`` - end-to-end vectors produced by the (pinned
+   where possible) oracle itself: seed, clip spec, per-frame fgr/pha at a tiny
+   size, final r1..r4.  They freeze the oracle against accidental edits and
+   give the GPU tests a fixture that does not need the oracle to run.
+
+Usage:  python oracle/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import rvm_oracle as O                      # noqa: E402
+from robustvideomatting_amd import spec, synthetic      # noqa: E402
+
+REF = "/root/reference/model"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name):
+    sp = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, name + ".py"))
+    m = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(m)
+    return m
+
+
+def _sub(params, prefix):
+    return {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+@torch.no_grad()
+def ref_blocks(variant):
+    torch.manual_seed(0)
+    dec_m, asp_m = _load("decoder"), _load("lraspp")
+    dgf_m, fgf_m = _load("deep_guided_filter"), _load("fast_guided_filter")
+    v = spec.VARIANTS[variant]
+    p = synthetic.make_params(variant, "deep_guided_filter", seed=3, perturb_box_filter=True)
+    g = torch.Generator().manual_seed(11)
+    h, w = 30, 54                                   # odd pyramid: 15x27, 8x14, 4x7, 2x4
+    (h1, w1), (h2, w2), (h3, w3), (h4, w4) = spec.pyramid_sizes(h, w)
+    T = 3
+    feat = v["feat"]
+    fix = {}
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    # ---- LR-ASPP
+    aspp = asp_m.LRASPP(v["enc_out"], v["aspp"]).eval()
+    aspp.load_state_dict(_sub(p, "aspp."))
+    x = rnd(2, v["enc_out"], h4, w4)
+    y_ref = aspp(x)
+    y_or = O.lraspp(p, x)
+    fix["aspp_in"], fix["aspp_out"] = x, y_ref
+    print("lraspp     max|ref-oracle| = %.3g" % (y_ref - y_or).abs().max())
+    assert (y_ref - y_or).abs().max() < 1e-6
+
+    # ---- decoder: frame-by-frame with state carry, then the 5-D time-series path
+    dec = dec_m.RecurrentDecoder(feat, v["dec"]).eval()
+    dec.load_state_dict(_sub(p, "decoder."))
+    s0 = torch.rand(1, T, 3, h, w, generator=g)
+    f1, f2 = rnd(1, T, feat[0], h1, w1) * 0.7, rnd(1, T, feat[1], h2, w2) * 0.7
+    f3, f4 = rnd(1, T, feat[2], h3, w3) * 0.7, rnd(1, T, feat[3], h4, w4).abs() * 0.7
+    rec_ref = [None] * 4
+    rec_or = [None] * 4
+    hid_ref = []
+    for t in range(T):
+        o_ref = dec(s0[:, t], f1[:, t], f2[:, t], f3[:, t], f4[:, t], *rec_ref)
+        o_or = O.decoder(p, s0[:, t], f1[:, t], f2[:, t], f3[:, t], f4[:, t], *rec_or)
+        for a, b in zip(o_ref, o_or):
+            assert (a - b).abs().max() < 1e-6, (a - b).abs().max()
+        rec_ref, rec_or = list(o_ref[1:]), list(o_or[1:])
+        hid_ref.append(o_ref[0])
+    o_ts = dec(s0, f1, f2, f3, f4, None, None, None, None)       # time-series path
+    d_ts = (o_ts[0] - torch.stack(hid_ref, 1)).abs().max()
+    print("decoder    frame-by-frame == reference time-series path: %.3g" % d_ts)
+    assert d_ts < 1e-5
+    for a, b in zip(o_ts[1:], rec_ref):
+        assert (a - b).abs().max() < 1e-5
+    fix.update(dec_s0=s0, dec_f1=f1, dec_f2=f2, dec_f3=f3, dec_f4=f4,
+               dec_hid=torch.stack(hid_ref, 1), dec_r1=rec_ref[0], dec_r2=rec_ref[1],
+               dec_r3=rec_ref[2], dec_r4=rec_ref[3])
+    print("decoder    oracle == reference classes over T=%d frames" % T)
+
+    # ---- projection (decoder.py:193-199)
+    proj = dec_m.Projection(16, 4).eval()
+    proj.load_state_dict(_sub(p, "project_mat."))
+    y = proj(hid_ref[0])
+    fix["proj_out"] = y
+
+    # ---- refiners
+    H, W = 4 * h + 1, 4 * w + 2                      # floor(H*0.25)=h, floor(W*0.25)=w, not exact multiples
+    fine = torch.rand(1, 3, H, W, generator=g)
+    base = torch.rand(1, 3, h, w, generator=g)
+    fgr, pha, hid = rnd(1, 3, h, w) * 0.2, torch.rand(1, 1, h, w, generator=g), hid_ref[0]
+    dgf = dgf_m.DeepGuidedFilterRefiner().eval()
+    dgf.load_state_dict(_sub(p, "refiner."))
+    a_ref = dgf(fine, base, fgr, pha, hid)
+    a_or = O.deep_guided_filter(p, fine, base, fgr, pha, hid)
+    fgf = fgf_m.FastGuidedFilterRefiner().eval()
+    b_ref = fgf(fine, base, fgr, pha, hid)
+    b_or = O.fast_guided_filter(fine, base, fgr, pha)
+    for a, b in zip(a_ref + b_ref, a_or + b_or):
+        assert (a - b).abs().max() < 1e-5, (a - b).abs().max()
+    print("refiners   oracle == reference classes (deep + fast)")
+    fix.update(ref_fine=fine, ref_base=base, ref_fgr=fgr, ref_pha=pha,
+               dgf_fgr=a_ref[0], dgf_pha=a_ref[1], fgf_fgr=b_ref[0], fgf_pha=b_ref[1])
+    np.savez_compressed(os.path.join(OUT, "ref_blocks_%s.npz" % variant),
+                        **{k: v_.numpy().astype(np.float32) for k, v_ in fix.items()})
+
+
+@torch.no_grad()
+def e2e(variant, refiner, tag, H, W, ds, T, seed):
+    p = synthetic.make_params(variant, refiner, seed=seed)
+    clip = synthetic.make_clip(T, H, W, seed=seed)
+    rec = [None] * 4
+    fgrs, phas = [], []
+    for t in range(T):
+        o = O.forward(p, clip[:, t], *rec, downsample_ratio=ds, variant=variant, refiner=refiner)
+        rec = o[2:]
+        fgrs.append(o[0])
+        phas.append(o[1])
+    fgr, pha = torch.stack(fgrs, 1), torch.stack(phas, 1)
+    print("e2e %-12s %-9s fgr mean %.4f  pha mean %.4f  pha in (0,1): %.1f%%" % (
+        variant, tag, fgr.mean(), pha.mean(), 100 * ((pha > 0) & (pha < 1)).float().mean()))
+    np.savez_compressed(
+        os.path.join(OUT, "e2e_%s_%s.npz" % (variant, tag)),
+        meta=np.array([H, W, T, seed], dtype=np.int64), ds=np.array(ds, dtype=np.float64),
+        refiner=np.array(refiner),
+        fgr=fgr.numpy().astype(np.float16), pha=pha.numpy().astype(np.float32),
+        fgr_last=fgr[:, -1].numpy(), r1=rec[0].numpy(), r2=rec[1].numpy(), r3=rec[2].numpy(), r4=rec[3].numpy())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_blocks("mobilenetv3")
+    ref_blocks("resnet50")
+    e2e("mobilenetv3", "deep_guided_filter", "ds025", 122, 218, 0.25, 4, 5)
+    e2e("mobilenetv3", "deep_guided_filter", "ds1", 36, 62, 1.0, 4, 6)
+    e2e("mobilenetv3", "fast_guided_filter", "fast", 122, 218, 0.25, 2, 7)
+    e2e("resnet50", "deep_guided_filter", "ds025", 122, 218, 0.25, 2, 8)
