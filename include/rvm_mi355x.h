@@ -1,0 +1,78 @@
+/* rvm_mi355x.h - C ABI of librvm_mi355x.so: RVM per-frame matting inference on AMD MI355X (gfx950).
+ *
+ * The reference (caixin98/RobustVideoMatting) has no FFI / plugin interface: its hot path is the
+ * Python method MattingNetwork.forward (model/model.py:40-71).  This header is the boundary a
+ * binding for that path would use; the Python class robustvideomatting_amd.MattingNetwork binds it
+ * with ctypes.  Plain pointers and sizes only - no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; rvm_last_error() gives the text
+ *     (thread-local).  No exception or abort crosses this boundary.
+ *   - src / fgr / pha are dense NCHW device buffers of the context's dtype.
+ *   - recurrent states r1..r4 are device buffers with LOGICAL shape [B, C, h, w] stored
+ *     channels-last (memory order B, h, w, C; torch.channels_last).  rvm_state_shape gives B,C,h,w.
+ *   - all work is enqueued on the given hipStream_t (passed as void*); no host sync inside
+ *     rvm_forward.  A context is not thread-safe; distinct contexts may be driven concurrently.
+ */
+#ifndef RVM_MI355X_H
+#define RVM_MI355X_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvm_ctx rvm_ctx;
+
+enum { RVM_DTYPE_F32 = 0, RVM_DTYPE_F16 = 1 };
+enum { RVM_VARIANT_MOBILENETV3 = 0, RVM_VARIANT_RESNET50 = 1 };
+enum { RVM_REFINER_DEEP_GUIDED_FILTER = 0, RVM_REFINER_FAST_GUIDED_FILTER = 1 };
+
+/* MattingNetwork.__init__(variant, refiner)  - model/model.py:15-38.  `device` is the HIP ordinal. */
+int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out);
+void rvm_destroy(rvm_ctx* ctx);
+
+/* The state_dict contract (inference.py:165 load_state_dict): names and shapes are exactly the
+ * reference's keys.  num_batches_tracked entries are listed with ndim 0 and may be
+ * left unset. */
+int rvm_param_count(const rvm_ctx* ctx);
+const char* rvm_param_name(const rvm_ctx* ctx, int index);
+int rvm_param_shape(const rvm_ctx* ctx, int index, int64_t shape[4]);   /* returns ndim, -1 on error */
+/* Copy one fp32 HOST tensor (contiguous, PyTorch layout) into the context. */
+int rvm_set_param(rvm_ctx* ctx, const char* name, const float* host_data, int64_t numel);
+/* Fold BatchNorm (eval), pack MFMA weight fragments in the context dtype, upload.  Call after all
+ * parameters are set and again whenever they change (module.to()/half()/load_state_dict). */
+int rvm_finalize(rvm_ctx* ctx);
+
+/* Fix the problem shape: src is [B,3,H,W]; downsample_ratio as in forward().  Allocates the
+ * activation arena (hipMalloc) - call outside any timed / captured region.  Re-planning is allowed. */
+int rvm_plan(rvm_ctx* ctx, int B, int H, int W, double downsample_ratio);
+/* level = 1..4 -> {B, C, h, w} of r<level> for the current plan. */
+int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
+
+/* MattingNetwork.forward on one frame batch (model/model.py:40-71).
+ *   r_in[i]  : previous state r<i+1> or NULL (= zeros, decoder.py:183-185)
+ *   r_out[i] : receives the new state; must not alias r_in[i]
+ *   seg_pass : 0 -> fgr [B,3,H,W] and pha [B,1,H,W] are written
+ *              1 -> `pha` receives project_seg(hid) [B,1,h,w] (model.py:69-71), fgr is ignored
+ * T>1 inputs are fed frame by frame by the caller (the recurrence is sequential, decoder.py:174-180). */
+int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* fgr, void* pha,
+                void* const r_out[4], int seg_pass, void* hip_stream);
+
+/* Debug / test taps: copy an intermediate activation of the LAST forward to host as fp32 NCHW.
+ * Names: s0 s1 s2 s3 f1 f2 f3 f4 aspp x3 x2 x1 hid ab.  Synchronises the device. */
+int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capacity, int64_t shape[4]);
+
+/* Number of kernel launches one rvm_forward enqueues for the current plan. */
+int rvm_launch_count(const rvm_ctx* ctx);
+
+/* HIP-graph replay of the fixed per-frame schedule (pointers must stay the same between calls
+ * for a replay to be valid; the graph is re-captured when they change). 0 = eager (default). */
+int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
+
+const char* rvm_last_error(void);
+const char* rvm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

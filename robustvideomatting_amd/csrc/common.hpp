@@ -1,0 +1,108 @@
+// Shared device/host definitions for the RVM MI355X (gfx950) engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Tr;
+template <> struct Tr<f16> {
+    typedef f16x4 v4;
+    typedef f16x8 v8;
+    static constexpr int kLdsPad = 8;   // elements of padding per LDS pixel row (16 B)
+};
+template <> struct Tr<float> {
+    typedef f32x4 v4;
+    typedef f32x8 v8;
+    static constexpr int kLdsPad = 4;
+};
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3, ACT_SIGMOID = 4 };
+
+// ---- pointwise (1x1) GEMM ----------------------------------------------------------------
+struct PwArgs {
+    const void* x;  int Cin; int xs;        // activations [N][HW][xs], Cin % 8 == 0
+    const void* w;  int KS;                 // weight fragments [NT][KS][64][8]
+    const float* bias;                      // [NT*16]
+    const void* in_scale;                   // T [N][Cin] (squeeze-excite) or null
+    const void* res; int rs;                // residual T [N][HW][rs] or null
+    const float* out_scale; int oss;        // float [N][oss] (LR-ASPP gate) or null
+    void* y; int Cout; int ys;              // out [N][HW][ys]
+    float* pool;                            // [N][MT][NT*16] per-m-tile column sums or null
+    int HW; int MT; int NT; int act;
+};
+
+// ---- depthwise conv ----------------------------------------------------------------------
+struct DwArgs {
+    const void* x; void* y;
+    const float* w;                         // [K*K][C] (BN folded)
+    const float* bias;                      // [C]
+    float* pool;                            // [N][nblk][C] partial sums of the output or null
+    int C, Hi, Wi, Ho, Wo, stride, dil, pad, act, ppb, nblk;
+};
+
+// ---- small dense layer on pooled vectors (SE fc1/fc2, LR-ASPP gate) ------------------------
+struct GemvArgs {
+    const float* xin; int nparts; int part_stride; float xscale;   // x[i] = xscale * sum_p xin[(n*nparts+p)*part_stride+i]
+    const void* w;                          // T [O][I]
+    const float* bias;                      // [O] or null
+    void* y; int y_is_T;                    // [N][O] float or T
+    int I, O, act, opw;                     // opw = outputs per wave
+};
+
+// ---- 3x3 implicit-GEMM conv (decoder, ConvGRU) ----------------------------------------------
+struct ConvSrc { const void* p; int C; int Cs; int up; int Hs; int Ws; };
+enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
+struct ConvArgs {
+    ConvSrc src[4]; int nsrc; int Cpad; int ql_log2;
+    const void* w; int KS; int NT; const float* bias;
+    int H, W, tiles_x, epi;
+    void* y; int Cout; int ys;              // EPI_RELU
+    const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
+    void* rh; float* z;                     // GRU scratch [N][H][W][hC]
+    void* hout;                             // GRU new state [N][H][W][hC]
+};
+
+// ---- stem ---------------------------------------------------------------------------------
+struct StemArgs {
+    const void* s0; void* y; const float* w /*[27][16]*/; const float* bias /*[16]*/;
+    int Hi, Wi, Ho, Wo; float mean[3]; float std_[3];
+};
+
+// ---- resize / pyramid ----------------------------------------------------------------------
+struct DownArgs { const void* src; void* s0; int H, W, h, w; float scale_y, scale_x; };
+struct PoolArgs { const void* x; void* y; int Hi, Wi, Ho, Wo; };
+
+// ---- refiner ------------------------------------------------------------------------------
+struct DgfWeights {                          // device blob layout (floats)
+    float proj_w[4][16]; float proj_b[4];
+    float box[4][9];
+    float w1[16][24]; float b1[16];
+    float w2[16][16]; float b2[16];
+    float w3[4][16];  float b3[4];
+    float seg_w[16];  float seg_b;
+};
+struct DgfLowArgs { const void* hid; const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast; };
+struct DgfApplyArgs {
+    const void* src; const float* ab; void* fgr; void* pha;
+    int H, W, h, w; float scale_y, scale_x;
+};
+struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; void* fgr; void* pha; int H, W, seg; };
+
+// launchers (kernels.hip)
+template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);
+template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s);
+template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
+template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, hipStream_t s);
+template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s);
+template <typename T> void launch_down(const DownArgs& a, int N, hipStream_t s);
+template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
+template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, hipStream_t s);
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, hipStream_t s);
+template <typename T> size_t conv3_lds_bytes(int MW, int Cpad);
+void kernels_init();   // one-time function attributes (dynamic LDS limits)

@@ -1,0 +1,892 @@
+// Host side of librvm_mi355x.so: parameter store, BatchNorm folding, MFMA fragment packing,
+// activation arena, the fixed per-frame kernel schedule and the C ABI (include/rvm_mi355x.h).
+//
+// The schedule mirrors MattingNetwork.forward (reference model/model.py:40-71):
+//   downsample -> encoder -> LR-ASPP -> recurrent decoder -> projection -> refiner -> clamp
+// but as ~75 fused launches on NHWC buffers instead of ~110 ATen ops on NCHW.
+#include "common.hpp"
+#include "../../include/rvm_mi355x.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// architecture tables (reference model/mobilenetv3.py:9-27, model/model.py:23-33)
+// ---------------------------------------------------------------------------------------------
+struct MbRow { int cin, k, exp, cout; bool se; int act; int stride, dil; };
+const MbRow kMbRows[15] = {
+    {16, 3, 16, 16, false, ACT_RELU, 1, 1},   {16, 3, 64, 24, false, ACT_RELU, 2, 1},
+    {24, 3, 72, 24, false, ACT_RELU, 1, 1},   {24, 5, 72, 40, true, ACT_RELU, 2, 1},
+    {40, 5, 120, 40, true, ACT_RELU, 1, 1},   {40, 5, 120, 40, true, ACT_RELU, 1, 1},
+    {40, 3, 240, 80, false, ACT_HSWISH, 2, 1}, {80, 3, 200, 80, false, ACT_HSWISH, 1, 1},
+    {80, 3, 184, 80, false, ACT_HSWISH, 1, 1}, {80, 3, 184, 80, false, ACT_HSWISH, 1, 1},
+    {80, 3, 480, 112, true, ACT_HSWISH, 1, 1}, {112, 3, 672, 112, true, ACT_HSWISH, 1, 1},
+    {112, 5, 672, 160, true, ACT_HSWISH, 2, 2}, {160, 5, 960, 160, true, ACT_HSWISH, 1, 2},
+    {160, 5, 960, 160, true, ACT_HSWISH, 1, 2},
+};
+int make_divisible(int v, int d) {
+    int nv = std::max(d, (v + d / 2) / d * d);
+    if (nv < 0.9 * v) nv += d;
+    return nv;
+}
+int se_squeeze(int exp) { return make_divisible(exp / 4, 8); }
+
+struct ParamSpec { std::string name; std::vector<int64_t> shape; };
+
+void add_bn(std::vector<ParamSpec>& v, const std::string& p, int c) {
+    v.push_back({p + ".weight", {c}});
+    v.push_back({p + ".bias", {c}});
+    v.push_back({p + ".running_mean", {c}});
+    v.push_back({p + ".running_var", {c}});
+    v.push_back({p + ".num_batches_tracked", {}});
+}
+
+std::vector<ParamSpec> param_specs(int variant, int refiner) {
+    std::vector<ParamSpec> v;
+    int enc_out, aspp, feat[4], dec[4];
+    if (variant == RVM_VARIANT_MOBILENETV3) {
+        enc_out = 960; aspp = 128;
+        int f[4] = {16, 24, 40, 128}, d[4] = {80, 40, 32, 16};
+        memcpy(feat, f, sizeof f); memcpy(dec, d, sizeof d);
+        v.push_back({"backbone.features.0.0.weight", {16, 3, 3, 3}});
+        add_bn(v, "backbone.features.0.1", 16);
+        for (int i = 0; i < 15; ++i) {
+            const MbRow& r = kMbRows[i];
+            std::string p = "backbone.features." + std::to_string(i + 1) + ".block.";
+            int j = 0;
+            if (r.exp != r.cin) {
+                v.push_back({p + std::to_string(j) + ".0.weight", {r.exp, r.cin, 1, 1}});
+                add_bn(v, p + std::to_string(j) + ".1", r.exp); ++j;
+            }
+            v.push_back({p + std::to_string(j) + ".0.weight", {r.exp, 1, r.k, r.k}});
+            add_bn(v, p + std::to_string(j) + ".1", r.exp); ++j;
+            if (r.se) {
+                int sq = se_squeeze(r.exp);
+                v.push_back({p + std::to_string(j) + ".fc1.weight", {sq, r.exp, 1, 1}});
+                v.push_back({p + std::to_string(j) + ".fc1.bias", {sq}});
+                v.push_back({p + std::to_string(j) + ".fc2.weight", {r.exp, sq, 1, 1}});
+                v.push_back({p + std::to_string(j) + ".fc2.bias", {r.exp}});
+                ++j;
+            }
+            v.push_back({p + std::to_string(j) + ".0.weight", {r.cout, r.exp, 1, 1}});
+            add_bn(v, p + std::to_string(j) + ".1", r.cout);
+        }
+        v.push_back({"backbone.features.16.0.weight", {960, 160, 1, 1}});
+        add_bn(v, "backbone.features.16.1", 960);
+    } else {
+        enc_out = 2048; aspp = 256;
+        int f[4] = {64, 256, 512, 256}, d[4] = {128, 64, 32, 16};
+        memcpy(feat, f, sizeof f); memcpy(dec, d, sizeof d);
+        v.push_back({"backbone.conv1.weight", {64, 3, 7, 7}});
+        add_bn(v, "backbone.bn1", 64);
+        const int nblk[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+        int inpl = 64;
+        for (int l = 0; l < 4; ++l)
+            for (int b = 0; b < nblk[l]; ++b) {
+                std::string p = "backbone.layer" + std::to_string(l + 1) + "." + std::to_string(b);
+                v.push_back({p + ".conv1.weight", {planes[l], inpl, 1, 1}});
+                add_bn(v, p + ".bn1", planes[l]);
+                v.push_back({p + ".conv2.weight", {planes[l], planes[l], 3, 3}});
+                add_bn(v, p + ".bn2", planes[l]);
+                v.push_back({p + ".conv3.weight", {planes[l] * 4, planes[l], 1, 1}});
+                add_bn(v, p + ".bn3", planes[l] * 4);
+                if (b == 0) {
+                    v.push_back({p + ".downsample.0.weight", {planes[l] * 4, inpl, 1, 1}});
+                    add_bn(v, p + ".downsample.1", planes[l] * 4);
+                }
+                inpl = planes[l] * 4;
+            }
+    }
+    v.push_back({"aspp.aspp1.0.weight", {aspp, enc_out, 1, 1}});
+    add_bn(v, "aspp.aspp1.1", aspp);
+    v.push_back({"aspp.aspp2.1.weight", {aspp, enc_out, 1, 1}});
+    auto gru = [&](const std::string& p, int c) {
+        v.push_back({p + ".ih.0.weight", {2 * c, 2 * c, 3, 3}});
+        v.push_back({p + ".ih.0.bias", {2 * c}});
+        v.push_back({p + ".hh.0.weight", {c, 2 * c, 3, 3}});
+        v.push_back({p + ".hh.0.bias", {c}});
+    };
+    gru("decoder.decode4.gru", feat[3] / 2);
+    const char* un[3] = {"decode3", "decode2", "decode1"};
+    int uin[3] = {feat[3], dec[0], dec[1]}, usk[3] = {feat[2], feat[1], feat[0]}, uout[3] = {dec[0], dec[1], dec[2]};
+    for (int i = 0; i < 3; ++i) {
+        std::string p = std::string("decoder.") + un[i];
+        v.push_back({p + ".conv.0.weight", {uout[i], uin[i] + usk[i] + 3, 3, 3}});
+        add_bn(v, p + ".conv.1", uout[i]);
+        gru(p + ".gru", uout[i] / 2);
+    }
+    v.push_back({"decoder.decode0.conv.0.weight", {dec[3], dec[2] + 3, 3, 3}});
+    add_bn(v, "decoder.decode0.conv.1", dec[3]);
+    v.push_back({"decoder.decode0.conv.3.weight", {dec[3], dec[3], 3, 3}});
+    add_bn(v, "decoder.decode0.conv.4", dec[3]);
+    v.push_back({"project_mat.conv.weight", {4, 16, 1, 1}});
+    v.push_back({"project_mat.conv.bias", {4}});
+    v.push_back({"project_seg.conv.weight", {1, 16, 1, 1}});
+    v.push_back({"project_seg.conv.bias", {1}});
+    if (refiner == RVM_REFINER_DEEP_GUIDED_FILTER) {
+        v.push_back({"refiner.box_filter.weight", {4, 1, 3, 3}});
+        v.push_back({"refiner.conv.0.weight", {16, 24, 1, 1}});
+        add_bn(v, "refiner.conv.1", 16);
+        v.push_back({"refiner.conv.3.weight", {16, 16, 1, 1}});
+        add_bn(v, "refiner.conv.4", 16);
+        v.push_back({"refiner.conv.6.weight", {4, 16, 1, 1}});
+        v.push_back({"refiner.conv.6.bias", {4}});
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed layers (offsets into the device weight blob)
+// ---------------------------------------------------------------------------------------------
+struct PwLayer { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, KS = 0, NT = 0, act = 0; };
+struct DwLayer { size_t w = 0, bias = 0; int C = 0, K = 3, stride = 1, dil = 1, pad = 1, act = 0; };
+struct SeLayer { size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };
+struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0; };
+struct GruLayer { Conv3Layer ih, hh; int C = 0; };
+struct MbBlock { bool has_expand = false, has_se = false, res = false; PwLayer expand, project; DwLayer dw; SeLayer se; MbRow row; };
+
+struct Tap { const void* p; int B, H, W, C, Cs; bool is_float; };
+
+struct FrameIO {
+    const void* src; const void* r_in[4]; void* fgr; void* pha; void* r_out[4]; int64_t seg;
+    bool operator==(const FrameIO& o) const { return memcmp(this, &o, sizeof(FrameIO)) == 0; }
+};
+
+}  // namespace
+
+struct rvm_ctx {
+    int variant, refiner, dtype, device;
+    std::vector<ParamSpec> specs;
+    std::map<std::string, std::vector<float>> params;
+    bool finalized = false;
+
+    // packed weights
+    std::vector<char> blob;
+    char* wdev = nullptr;
+    size_t stem_w = 0, stem_b = 0;
+    MbBlock mb[15];
+    PwLayer last, aspp1;
+    size_t aspp2_w = 0;
+    int enc_out = 0, aspp_c = 0, feat[4], dec[4];
+    GruLayer gru[4];            // decode4, decode3, decode2, decode1
+    Conv3Layer up[3];           // decode3, decode2, decode1
+    Conv3Layer out0, out1;      // decode0 conv.0, conv.3
+    size_t dgf = 0;
+
+    // plan
+    bool planned = false;
+    int B = 0, H = 0, W = 0, h = 0, w = 0;
+    double ds = 1;
+    int lh[5], lw[5];
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    std::vector<std::function<void(hipStream_t, const FrameIO&)>> launches;
+    std::map<std::string, Tap> taps;
+
+    // graph mode
+    bool graph_mode = false;
+    hipStream_t cap_stream = nullptr;
+    struct GraphEntry { FrameIO key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+
+    size_t esize() const { return dtype == RVM_DTYPE_F16 ? 2 : 4; }
+    const std::vector<float>* P(const std::string& n) const {
+        auto it = params.find(n);
+        return it == params.end() ? nullptr : &it->second;
+    }
+    size_t blob_alloc(size_t bytes) {
+        size_t off = (blob.size() + 255) & ~size_t(255);
+        blob.resize(off + bytes, 0);
+        return off;
+    }
+    void* arena_alloc(size_t bytes) {
+        size_t off = (arena_used + 255) & ~size_t(255);
+        arena_used = off + bytes;
+        return arena + off;     // arena == nullptr during the sizing pass
+    }
+    void drop_graphs() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// folding / packing
+// ---------------------------------------------------------------------------------------------
+struct Affine { std::vector<float> scale, shift; };
+
+bool bn_fold(const rvm_ctx* c, const std::string& p, int n, float eps, Affine& a) {
+    auto g = c->P(p + ".weight"), b = c->P(p + ".bias"), m = c->P(p + ".running_mean"), v = c->P(p + ".running_var");
+    if (!g || !b || !m || !v) { g_err = "missing BatchNorm parameters: " + p; return false; }
+    a.scale.resize(n); a.shift.resize(n);
+    for (int i = 0; i < n; ++i) {
+        float s = (*g)[i] / std::sqrt((*v)[i] + eps);
+        a.scale[i] = s;
+        a.shift[i] = (*b)[i] - (*m)[i] * s;
+    }
+    return true;
+}
+Affine identity_affine(int n, const std::vector<float>* bias) {
+    Affine a; a.scale.assign(n, 1.f); a.shift.assign(n, 0.f);
+    if (bias) for (int i = 0; i < n; ++i) a.shift[i] = (*bias)[i];
+    return a;
+}
+
+void put_elems(rvm_ctx* c, size_t off, const std::vector<float>& v) {
+    if (c->dtype == RVM_DTYPE_F16) {
+        f16* d = (f16*)(c->blob.data() + off);
+        for (size_t i = 0; i < v.size(); ++i) d[i] = (f16)v[i];
+    } else {
+        memcpy(c->blob.data() + off, v.data(), v.size() * 4);
+    }
+}
+size_t put_floats(rvm_ctx* c, const std::vector<float>& v) {
+    size_t off = c->blob_alloc(v.size() * 4);
+    memcpy(c->blob.data() + off, v.data(), v.size() * 4);
+    return off;
+}
+
+// W[out][in][KK] -> MFMA fragments [NT][KS][64 lanes][8], k = tap*Cpad + packed_channel.
+// out_map[po] / in_map[pc] give the original index or -1 (zero row / column).
+void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const std::vector<int>& out_map,
+                const std::vector<int>& in_map, const Affine& af, size_t& w_off, size_t& b_off, int& KS, int& NT) {
+    const int Cpad = (int)in_map.size();
+    const int K = KK * Cpad;
+    KS = cdiv(K, 32);
+    NT = (int)out_map.size() / 16;
+    std::vector<float> fr((size_t)NT * KS * 512, 0.f), bias((size_t)NT * 16, 0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = out_map[nt * 16 + (lane & 15)];
+                if (o < 0) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 32 + 8 * (lane >> 4) + j;
+                    if (k >= K) continue;
+                    const int tap = k / Cpad, i = in_map[k % Cpad];
+                    if (i < 0) continue;
+                    fr[(((size_t)nt * KS + ks) * 64 + lane) * 8 + j] = W[((size_t)o * Cin + i) * KK + tap] * af.scale[o];
+                }
+            }
+    for (size_t po = 0; po < out_map.size(); ++po)
+        if (out_map[po] >= 0) bias[po] = af.shift[out_map[po]];
+    w_off = c->blob_alloc(fr.size() * c->esize());
+    put_elems(c, w_off, fr);
+    b_off = put_floats(c, bias);
+}
+
+std::vector<int> iota_map(int n, int padded) {
+    std::vector<int> m(padded, -1);
+    for (int i = 0; i < n; ++i) m[i] = i;
+    return m;
+}
+
+bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, int Cout, int act, PwLayer& L) {
+    auto W = c->P(wname);
+    if (!W) { g_err = "missing parameter " + wname; return false; }
+    L.Cin = Cin; L.Cout = Cout; L.act = act;
+    pack_frags(c, *W, Cin, 1, iota_map(Cout, rup(Cout, 16)), iota_map(Cin, rup(Cin, 8)), af, L.w, L.bias, L.KS, L.NT);
+    return true;
+}
+
+// srcC: channels of each concatenated source as the kernel sees them (multiples of 4);
+// srcOrig: how many of them are real reference channels (the rest, e.g. the gray lane of the
+// NHWC4 image sources, get zero weights).
+bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
+                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L) {
+    auto W = c->P(wname);
+    if (!W) { g_err = "missing parameter " + wname; return false; }
+    int tot = 0, cin = 0;
+    for (int x : srcC) tot += x;
+    for (int x : srcOrig) cin += x;
+    std::vector<int> in_map(rup(tot, 8), -1);
+    int pc = 0, oc = 0;
+    for (size_t s = 0; s < srcC.size(); ++s) {
+        for (int k = 0; k < srcOrig[s]; ++k) in_map[pc + k] = oc + k;
+        pc += srcC[s]; oc += srcOrig[s];
+    }
+    L.Cpad = (int)in_map.size(); L.Cout = Cout;
+    pack_frags(c, *W, cin, 9, out_map, in_map, af, L.w, L.bias, L.KS, L.NT);
+    return true;
+}
+
+bool pack_gru(rvm_ctx* c, const std::string& p, int C, GruLayer& G) {
+    G.C = C;
+    auto bih = c->P(p + ".ih.0.bias"), bhh = c->P(p + ".hh.0.bias");
+    if (!bih || !bhh) { g_err = "missing parameter " + p + ".{ih,hh}.0.bias"; return false; }
+    // ih: packed tile 2j = r[16j..16j+15], 2j+1 = z[16j..]
+    const int ct = cdiv(C, 16);
+    std::vector<int> om(ct * 32, -1);
+    for (int j = 0; j < ct; ++j)
+        for (int i = 0; i < 16; ++i) {
+            int ch = j * 16 + i;
+            if (ch < C) { om[(2 * j) * 16 + i] = ch; om[(2 * j + 1) * 16 + i] = C + ch; }
+        }
+    if (!pack_conv3(c, p + ".ih.0.weight", identity_affine(2 * C, bih), 2 * C, om, {C, C}, {C, C}, G.ih)) return false;
+    if (!pack_conv3(c, p + ".hh.0.weight", identity_affine(C, bhh), C, iota_map(C, rup(C, 16)), {C, C}, {C, C}, G.hh)) return false;
+    return true;
+}
+
+int finalize_impl(rvm_ctx* c) {
+    for (auto& s : c->specs) {
+        if (s.shape.empty()) continue;
+        if (!c->P(s.name)) return fail("rvm_finalize: parameter not set: " + s.name);
+    }
+    c->blob.clear();
+    if (c->variant != RVM_VARIANT_MOBILENETV3) return fail("rvm_finalize: resnet50 encoder is not implemented yet");
+    c->enc_out = 960; c->aspp_c = 128;
+    { int f[4] = {16, 24, 40, 128}, d[4] = {80, 40, 32, 16}; memcpy(c->feat, f, sizeof f); memcpy(c->dec, d, sizeof d); }
+    Affine af;
+    // stem
+    {
+        auto W = c->P("backbone.features.0.0.weight");
+        if (!bn_fold(c, "backbone.features.0.1", 16, 1e-3f, af)) return 1;
+        std::vector<float> w(27 * 16);
+        for (int o = 0; o < 16; ++o)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int t = 0; t < 9; ++t) w[(t * 3 + ci) * 16 + o] = (*W)[(o * 3 + ci) * 9 + t] * af.scale[o];
+        c->stem_w = put_floats(c, w);
+        c->stem_b = put_floats(c, af.shift);
+    }
+    for (int i = 0; i < 15; ++i) {
+        MbBlock& b = c->mb[i];
+        const MbRow& r = kMbRows[i];
+        b.row = r; b.has_expand = r.exp != r.cin; b.has_se = r.se; b.res = (r.stride == 1 && r.cin == r.cout);
+        std::string p = "backbone.features." + std::to_string(i + 1) + ".block.";
+        int j = 0;
+        if (b.has_expand) {
+            if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
+            if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.cin, r.exp, r.act, b.expand)) return 1;
+            ++j;
+        }
+        {
+            auto W = c->P(p + std::to_string(j) + ".0.weight");
+            if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
+            const int KK = r.k * r.k;
+            std::vector<float> w((size_t)KK * r.exp);
+            for (int ch = 0; ch < r.exp; ++ch)
+                for (int t = 0; t < KK; ++t) w[(size_t)t * r.exp + ch] = (*W)[(size_t)ch * KK + t] * af.scale[ch];
+            b.dw.w = put_floats(c, w);
+            b.dw.bias = put_floats(c, af.shift);
+            b.dw.C = r.exp; b.dw.K = r.k; b.dw.dil = r.dil; b.dw.stride = r.dil > 1 ? 1 : r.stride;
+            b.dw.pad = (r.k - 1) / 2 * r.dil; b.dw.act = r.act;
+            ++j;
+        }
+        if (b.has_se) {
+            const int S = se_squeeze(r.exp);
+            std::string q = p + std::to_string(j);
+            b.se.C = r.exp; b.se.S = S;
+            b.se.w1 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w1, *c->P(q + ".fc1.weight"));
+            b.se.b1 = put_floats(c, *c->P(q + ".fc1.bias"));
+            b.se.w2 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w2, *c->P(q + ".fc2.weight"));
+            b.se.b2 = put_floats(c, *c->P(q + ".fc2.bias"));
+            ++j;
+        }
+        if (!bn_fold(c, p + std::to_string(j) + ".1", r.cout, 1e-3f, af)) return 1;
+        if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.exp, r.cout, ACT_NONE, b.project)) return 1;
+    }
+    if (!bn_fold(c, "backbone.features.16.1", 960, 1e-3f, af)) return 1;
+    if (!pack_pw(c, "backbone.features.16.0.weight", af, 160, 960, ACT_HSWISH, c->last)) return 1;
+    // LR-ASPP
+    if (!bn_fold(c, "aspp.aspp1.1", c->aspp_c, 1e-5f, af)) return 1;
+    if (!pack_pw(c, "aspp.aspp1.0.weight", af, c->enc_out, c->aspp_c, ACT_RELU, c->aspp1)) return 1;
+    c->aspp2_w = c->blob_alloc((size_t)c->aspp_c * c->enc_out * c->esize());
+    put_elems(c, c->aspp2_w, *c->P("aspp.aspp2.1.weight"));
+    // decoder
+    const int* feat = c->feat; const int* dec = c->dec;
+    if (!pack_gru(c, "decoder.decode4.gru", feat[3] / 2, c->gru[0])) return 1;
+    const char* un[3] = {"decode3", "decode2", "decode1"};
+    int uin[3] = {feat[3], dec[0], dec[1]}, usk[3] = {feat[2], feat[1], feat[0]}, uout[3] = {dec[0], dec[1], dec[2]};
+    for (int i = 0; i < 3; ++i) {
+        std::string p = std::string("decoder.") + un[i];
+        if (!bn_fold(c, p + ".conv.1", uout[i], 1e-5f, af)) return 1;
+        // sources: up(a) | up(h) | f | s(NHWC4)   == reference cat[x, f, s] with x = cat[a, h]
+        if (!pack_conv3(c, p + ".conv.0.weight", af, uout[i], iota_map(uout[i], rup(uout[i], 16)),
+                        {uin[i] / 2, uin[i] / 2, usk[i], 4}, {uin[i] / 2, uin[i] / 2, usk[i], 3}, c->up[i])) return 1;
+        if (!pack_gru(c, p + ".gru", uout[i] / 2, c->gru[i + 1])) return 1;
+    }
+    if (!bn_fold(c, "decoder.decode0.conv.1", dec[3], 1e-5f, af)) return 1;
+    if (!pack_conv3(c, "decoder.decode0.conv.0.weight", af, dec[3], iota_map(dec[3], 16),
+                    {dec[2] / 2, dec[2] / 2, 4}, {dec[2] / 2, dec[2] / 2, 3}, c->out0)) return 1;
+    if (!bn_fold(c, "decoder.decode0.conv.4", dec[3], 1e-5f, af)) return 1;
+    if (!pack_conv3(c, "decoder.decode0.conv.3.weight", af, dec[3], iota_map(dec[3], 16), {dec[3]}, {dec[3]}, c->out1)) return 1;
+    // projection + refiner constants
+    {
+        DgfWeights d; memset(&d, 0, sizeof d);
+        auto pw = c->P("project_mat.conv.weight"), pb = c->P("project_mat.conv.bias");
+        auto sw = c->P("project_seg.conv.weight"), sb = c->P("project_seg.conv.bias");
+        memcpy(d.proj_w, pw->data(), 64 * 4); memcpy(d.proj_b, pb->data(), 16);
+        memcpy(d.seg_w, sw->data(), 64); d.seg_b = (*sb)[0];
+        if (c->refiner == RVM_REFINER_DEEP_GUIDED_FILTER) {
+            memcpy(d.box, c->P("refiner.box_filter.weight")->data(), 36 * 4);
+            Affine a1, a2;
+            if (!bn_fold(c, "refiner.conv.1", 16, 1e-5f, a1) || !bn_fold(c, "refiner.conv.4", 16, 1e-5f, a2)) return 1;
+            auto w1 = c->P("refiner.conv.0.weight"), w2 = c->P("refiner.conv.3.weight"), w3 = c->P("refiner.conv.6.weight");
+            for (int o = 0; o < 16; ++o) {
+                for (int k = 0; k < 24; ++k) d.w1[o][k] = (*w1)[o * 24 + k] * a1.scale[o];
+                for (int k = 0; k < 16; ++k) d.w2[o][k] = (*w2)[o * 16 + k] * a2.scale[o];
+                d.b1[o] = a1.shift[o]; d.b2[o] = a2.shift[o];
+            }
+            memcpy(d.w3, w3->data(), 64 * 4);
+            memcpy(d.b3, c->P("refiner.conv.6.bias")->data(), 16);
+        } else {
+            const float t = 1.0f / 3.0f;
+            for (int ch = 0; ch < 4; ++ch) for (int k = 0; k < 9; ++k) d.box[ch][k] = t * t;
+        }
+        c->dgf = c->blob_alloc(sizeof d);
+        memcpy(c->blob.data() + c->dgf, &d, sizeof d);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->wdev) { HIPCHK(hipFree(c->wdev)); c->wdev = nullptr; }
+    HIPCHK(hipMalloc((void**)&c->wdev, c->blob.size()));
+    HIPCHK(hipMemcpy(c->wdev, c->blob.data(), c->blob.size(), hipMemcpyHostToDevice));
+    c->finalized = true;
+    c->planned = false;
+    c->launches.clear();
+    c->drop_graphs();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// schedule
+// ---------------------------------------------------------------------------------------------
+int pick_pw_cfg(int MT, int NT, int N) {
+    // block tile (m-tiles x n-tiles) of pw_gemm configs 0..3, in order of preference
+    const int bm[4] = {4, 2, 8, 2}, bn[4] = {4, 2, 1, 4};
+    const int pref[4] = {0, 3, 2, 1};
+    int best = 2, best_blocks = -1;
+    for (int k = 0; k < 4; ++k) {
+        const int cfg = pref[k];
+        if (bn[cfg] > 1 && cdiv(NT, bn[cfg]) * bn[cfg] >= 2 * NT) continue;   // more than half the tile idle
+        const int blocks = cdiv(MT, bm[cfg]) * cdiv(NT, bn[cfg]) * N;
+        if (blocks >= 256) return cfg;
+        if (blocks > best_blocks) { best_blocks = blocks; best = cfg; }
+    }
+    return best;
+}
+
+template <typename T>
+int build_plan(rvm_ctx* c) {
+    c->launches.clear();
+    c->taps.clear();
+    c->arena_used = 0;
+    const int B = c->B;
+    const size_t es = sizeof(T);
+    char* wb = c->wdev;
+    const int* lh = c->lh; const int* lw = c->lw;
+    auto abuf = [&](size_t elems) { return (T*)c->arena_alloc(elems * es); };
+    auto fbuf = [&](size_t elems) { return (float*)c->arena_alloc(elems * 4); };
+    auto add = [&](std::function<void(hipStream_t, const FrameIO&)> f) { c->launches.push_back(std::move(f)); };
+
+    // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
+    T* s[4];
+    for (int l = 0; l < 4; ++l) s[l] = abuf((size_t)B * lh[l] * lw[l] * 4);
+    {
+        DownArgs a; a.s0 = s[0]; a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w;
+        a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
+        add([=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, st); });
+        for (int l = 1; l < 4; ++l) {
+            PoolArgs p; p.x = s[l - 1]; p.y = s[l]; p.Hi = lh[l - 1]; p.Wi = lw[l - 1]; p.Ho = lh[l]; p.Wo = lw[l];
+            add([=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
+        }
+        for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
+    }
+
+    auto pw = [&](const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
+                  const float* out_scale, float* pool) {
+        PwArgs a; memset(&a, 0, sizeof a);
+        a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
+        a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
+        a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
+        const int cfg = pick_pw_cfg(a.MT, a.NT, B);
+        add([=](hipStream_t st, const FrameIO&) { launch_pw<T>(a, B, cfg, st); });
+    };
+
+    // ---- encoder (mobilenetv3.py:36-60)
+    T* cur = abuf((size_t)B * lh[1] * lw[1] * 16);
+    int curC = 16, lvl = 1;
+    {
+        StemArgs a; a.s0 = s[0]; a.y = cur; a.w = (const float*)(wb + c->stem_w); a.bias = (const float*)(wb + c->stem_b);
+        a.Hi = lh[0]; a.Wi = lw[0]; a.Ho = lh[1]; a.Wo = lw[1];
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+        for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
+        add([=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
+    }
+    T* f[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 15; ++i) {
+        const MbBlock& b = c->mb[i];
+        const int Hi = lh[lvl], Wi = lw[lvl];
+        const int olvl = b.dw.stride == 2 ? lvl + 1 : lvl;
+        const int Ho = lh[olvl], Wo = lw[olvl];
+        const int exp = b.row.exp;
+        const T* ex = cur;
+        if (b.has_expand) {
+            T* e = abuf((size_t)B * Hi * Wi * exp);
+            pw(b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
+            ex = e;
+        }
+        T* dwo = abuf((size_t)B * Ho * Wo * exp);
+        const int npix = Ho * Wo;
+        const int CG = exp / 8;
+        int PY = std::max(1, 256 / CG);
+        const int target = b.has_se ? 64 : 1024;
+        int ppb = rup(std::max(1, cdiv(npix, target)), PY);
+        const int nblk = cdiv(npix, ppb);
+        float* partial = b.has_se ? fbuf((size_t)B * nblk * exp) : nullptr;
+        {
+            DwArgs a; a.x = ex; a.y = dwo; a.w = (const float*)(wb + b.dw.w); a.bias = (const float*)(wb + b.dw.bias);
+            a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
+            a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
+            const int K = b.dw.K;
+            add([=](hipStream_t st, const FrameIO&) { launch_dw<T>(a, B, K, st); });
+        }
+        const T* scale = nullptr;
+        if (b.has_se) {
+            float* hidden = fbuf((size_t)B * b.se.S);
+            T* sc = abuf((size_t)B * exp);
+            GemvArgs g1; memset(&g1, 0, sizeof g1);
+            g1.xin = partial; g1.nparts = nblk; g1.part_stride = exp; g1.xscale = 1.f / (float)npix;
+            g1.w = wb + b.se.w1; g1.bias = (const float*)(wb + b.se.b1); g1.y = hidden; g1.y_is_T = 0;
+            g1.I = exp; g1.O = b.se.S; g1.act = ACT_RELU; g1.opw = 2;
+            GemvArgs g2; memset(&g2, 0, sizeof g2);
+            g2.xin = hidden; g2.nparts = 1; g2.part_stride = b.se.S; g2.xscale = 1.f;
+            g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
+            g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
+            add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
+            add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
+            scale = sc;
+        }
+        T* out = abuf((size_t)B * npix * b.row.cout);
+        pw(b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+        cur = out; curC = b.row.cout; lvl = olvl;
+        if (i == 0) f[0] = cur;
+        if (i == 2) f[1] = cur;
+        if (i == 5) f[2] = cur;
+    }
+    const int HW4 = lh[4] * lw[4];
+    T* f4 = abuf((size_t)B * HW4 * c->enc_out);
+    const int MT4 = cdiv(HW4, 16);
+    float* f4pool = fbuf((size_t)B * MT4 * c->last.NT * 16);
+    pw(c->last, cur, curC, HW4, f4, c->enc_out, nullptr, nullptr, 0, nullptr, f4pool);
+    c->taps["f1"] = Tap{f[0], B, lh[1], lw[1], c->feat[0], c->feat[0], false};
+    c->taps["f2"] = Tap{f[1], B, lh[2], lw[2], c->feat[1], c->feat[1], false};
+    c->taps["f3"] = Tap{f[2], B, lh[3], lw[3], c->feat[2], c->feat[2], false};
+    c->taps["f4"] = Tap{f4, B, lh[4], lw[4], c->enc_out, c->enc_out, false};
+
+    // ---- LR-ASPP (lraspp.py:17-18)
+    float* gate = fbuf((size_t)B * c->aspp_c);
+    {
+        GemvArgs g; memset(&g, 0, sizeof g);
+        g.xin = f4pool; g.nparts = MT4; g.part_stride = c->last.NT * 16; g.xscale = 1.f / (float)HW4;
+        g.w = wb + c->aspp2_w; g.bias = nullptr; g.y = gate; g.y_is_T = 0; g.I = c->enc_out; g.O = c->aspp_c;
+        g.act = ACT_SIGMOID; g.opw = 1;
+        add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g, B, st); });
+    }
+    const int AC = c->aspp_c;
+    T* aspp = abuf((size_t)B * HW4 * AC);
+    pw(c->aspp1, f4, c->enc_out, HW4, aspp, AC, nullptr, nullptr, 0, gate, nullptr);
+    c->taps["aspp"] = Tap{aspp, B, lh[4], lw[4], AC, AC, false};
+
+    // ---- recurrent decoder (decoder.py:17-27)
+    auto conv3 = [&](const Conv3Layer& L, int Hh, int Ww, int epi, std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
+        ConvArgs a; memset(&a, 0, sizeof a);
+        a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
+        a.H = Hh; a.W = Ww; a.tiles_x = cdiv(Ww, 16); a.epi = epi; a.Cout = L.Cout;
+        int ql = 0; while ((1 << ql) < (L.Cpad >> 2) && ql < 6) ++ql;
+        a.ql_log2 = ql;
+        // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
+        int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
+        const int mws[3] = {4, 2, 1};
+        int MW = 1;
+        for (int k = 0; k < 3; ++k) {
+            int m = mws[k];
+            if (NW == 2 && m == 4) continue;
+            if (conv3_lds_bytes<T>(m, L.Cpad) > 150 * 1024) continue;
+            int blocks = a.tiles_x * cdiv(Hh, 4 * m) * cdiv(L.NT, NW) * B;
+            if (blocks >= 256 || m == 1) { MW = m; break; }
+        }
+        if (conv3_lds_bytes<T>(MW, L.Cpad) > 160 * 1024) return fail("conv3x3: input patch does not fit LDS");
+        add([=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, st); });
+        return 0;
+    };
+    // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
+    auto gru = [&](const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
+        const int C = G.C;
+        T* rh = abuf((size_t)B * Hh * Ww * C);
+        float* z = fbuf((size_t)B * Hh * Ww * C);
+        if (conv3(G.ih, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
+                a.nsrc = 0;
+                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0}; a.nsrc = 2;
+                a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z;
+            })) return 1;
+        if (conv3(G.hh, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
+                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0}; a.nsrc = 2;
+                a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx];
+            })) return 1;
+        return 0;
+    };
+        // decode4 (BottleneckBlock, decoder.py:63-67): a = aspp[:, :AC/2], b = aspp[:, AC/2:]
+    if (gru(c->gru[0], aspp + AC / 2, AC, lh[4], lw[4], 3)) return 1;
+    const T* xa = aspp; int xaC = AC / 2, xaS = AC;   // first half of the previous block output
+    const T* skip[3] = {f[2], f[1], f[0]};
+    const int skipC[3] = {c->feat[2], c->feat[1], c->feat[0]};
+    for (int i = 0; i < 3; ++i) {
+        const int l = 3 - i;                        // output level 3,2,1
+        const int Cout = c->dec[i];
+        T* X = abuf((size_t)B * lh[l] * lw[l] * Cout);
+        const int hidx = 3 - i;                     // state produced by the previous block: r4, r3, r2
+        const T* sk = skip[i]; const int skC = skipC[i];
+        const T* sl = s[l];
+        const int Hs = lh[l + 1], Ws = lw[l + 1];
+        const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
+        if (conv3(c->up[i], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
+                a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws};
+                a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0};
+                a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0};
+                a.nsrc = 4; a.y = X; a.ys = Cout;
+            })) return 1;
+        if (gru(c->gru[i + 1], X + Cout / 2, Cout, lh[l], lw[l], hidx - 1)) return 1;
+        c->taps["x" + std::to_string(l)] = Tap{X, B, lh[l], lw[l], Cout, Cout, false};
+        xa = X; xaC = Cout / 2; xaS = Cout;
+    }
+    // decode0 (OutputBlock, decoder.py:127-131)
+    const int HC = c->dec[3];
+    T* hidA = abuf((size_t)B * c->h * c->w * HC);
+    T* hid = abuf((size_t)B * c->h * c->w * HC);
+    {
+        const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
+        const T* s0 = s[0];
+        const int Hs = lh[1], Ws = lw[1];
+        if (conv3(c->out0, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
+                a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws};
+                a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0};
+                a.nsrc = 3; a.y = hidA; a.ys = HC;
+            })) return 1;
+        if (conv3(c->out1, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
+                a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
+            })) return 1;
+    }
+    c->taps["hid"] = Tap{hid, B, c->h, c->w, HC, HC, false};
+
+    // ---- projection + refiner + clamp (model.py:61-68)
+    const DgfWeights* dw = (const DgfWeights*)(wb + c->dgf);
+    float* ab = fbuf((size_t)B * c->h * c->w * 8);
+    c->taps["ab"] = Tap{ab, B, c->h, c->w, 8, 8, true};
+    {
+        DgfLowArgs lo; lo.hid = hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
+        lo.fast = c->refiner == RVM_REFINER_FAST_GUIDED_FILTER;
+        DgfApplyArgs ap; ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
+        ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
+        ProjOutArgs po; po.hid = hid; po.wt = dw; po.H = c->h; po.W = c->w;
+        const bool refine = c->ds != 1.0;
+        add([=](hipStream_t st, const FrameIO& io) {
+            if (io.seg || !refine) {
+                ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = io.seg;
+                launch_proj_out<T>(q, B, st);
+            } else {
+                launch_dgf_low<T>(lo, B, st);
+                DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
+                launch_dgf_apply<T>(q, B, st);
+            }
+        });
+    }
+    return 0;
+}
+
+int plan_impl(rvm_ctx* c, int B, int H, int W, double ds) {
+    if (!c->finalized) return fail("rvm_plan: call rvm_finalize first");
+    if (B < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
+    if (!(ds > 0.0 && ds <= 1.0)) return fail("rvm_plan: downsample_ratio must be in (0, 1]");
+    c->B = B; c->H = H; c->W = W; c->ds = ds;
+    if (ds == 1.0) { c->h = H; c->w = W; }
+    else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
+    if (c->h < 1 || c->w < 1) return fail("rvm_plan: downsampled frame is empty");
+    c->lh[0] = c->h; c->lw[0] = c->w;
+    for (int l = 1; l < 5; ++l) { c->lh[l] = (c->lh[l - 1] + 1) / 2; c->lw[l] = (c->lw[l - 1] + 1) / 2; }
+    HIPCHK(hipSetDevice(c->device));
+    c->drop_graphs();
+    if (c->arena) { HIPCHK(hipFree(c->arena)); c->arena = nullptr; }
+    c->planned = false;
+    // sizing pass (arena == nullptr), then the real pass
+    int rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
+    if (rc) return rc;
+    c->arena_bytes = c->arena_used + 256;
+    HIPCHK(hipMalloc((void**)&c->arena, c->arena_bytes));
+    HIPCHK(hipMemset(c->arena, 0, c->arena_bytes));
+    rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
+    if (rc) return rc;
+    c->planned = true;
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* rvm_last_error(void) { return g_err.c_str(); }
+const char* rvm_version(void) { return "rvm_mi355x 0.1 (gfx950)"; }
+
+int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
+    if (!out) return fail("rvm_create: null out");
+    *out = nullptr;
+    if (variant != RVM_VARIANT_MOBILENETV3 && variant != RVM_VARIANT_RESNET50) return fail("rvm_create: bad variant");
+    if (refiner != RVM_REFINER_DEEP_GUIDED_FILTER && refiner != RVM_REFINER_FAST_GUIDED_FILTER) return fail("rvm_create: bad refiner");
+    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16) return fail("rvm_create: bad dtype");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("rvm_create: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    static bool inited[64] = {false};
+    if (device < 64 && !inited[device]) { kernels_init(); inited[device] = true; }
+    rvm_ctx* c = new rvm_ctx();
+    c->variant = variant; c->refiner = refiner; c->dtype = dtype; c->device = device;
+    c->specs = param_specs(variant, refiner);
+    *out = c;
+    return 0;
+}
+
+void rvm_destroy(rvm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->drop_graphs();
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->wdev) (void)hipFree(c->wdev);
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+}
+
+int rvm_param_count(const rvm_ctx* c) { return c ? (int)c->specs.size() : 0; }
+const char* rvm_param_name(const rvm_ctx* c, int i) {
+    if (!c || i < 0 || i >= (int)c->specs.size()) return nullptr;
+    return c->specs[i].name.c_str();
+}
+int rvm_param_shape(const rvm_ctx* c, int i, int64_t shape[4]) {
+    if (!c || i < 0 || i >= (int)c->specs.size()) { g_err = "rvm_param_shape: bad index"; return -1; }
+    const auto& s = c->specs[i].shape;
+    for (size_t k = 0; k < s.size(); ++k) shape[k] = s[k];
+    return (int)s.size();
+}
+
+int rvm_set_param(rvm_ctx* c, const char* name, const float* data, int64_t numel) {
+    if (!c || !name || !data) return fail("rvm_set_param: null argument");
+    for (auto& s : c->specs) {
+        if (s.name != name) continue;
+        int64_t n = 1;
+        for (auto d : s.shape) n *= d;
+        if (n != numel) return fail(std::string("rvm_set_param: size mismatch for ") + name);
+        c->params[name].assign(data, data + numel);
+        c->finalized = false;
+        return 0;
+    }
+    return fail(std::string("rvm_set_param: unexpected key ") + name);
+}
+
+int rvm_finalize(rvm_ctx* c) {
+    if (!c) return fail("rvm_finalize: null ctx");
+    return finalize_impl(c);
+}
+
+int rvm_plan(rvm_ctx* c, int B, int H, int W, double ds) {
+    if (!c) return fail("rvm_plan: null ctx");
+    return plan_impl(c, B, H, W, ds);
+}
+
+int rvm_state_shape(const rvm_ctx* c, int level, int64_t shape[4]) {
+    if (!c || !c->planned) return fail("rvm_state_shape: no plan");
+    if (level < 1 || level > 4) return fail("rvm_state_shape: level must be 1..4");
+    const int ch[4] = {c->dec[2] / 2, c->dec[1] / 2, c->dec[0] / 2, c->feat[3] / 2};
+    shape[0] = c->B; shape[1] = ch[level - 1]; shape[2] = c->lh[level]; shape[3] = c->lw[level];
+    return 0;
+}
+
+int rvm_launch_count(const rvm_ctx* c) { return c ? (int)c->launches.size() : 0; }
+
+int rvm_set_graph_mode(rvm_ctx* c, int enabled) {
+    if (!c) return fail("rvm_set_graph_mode: null ctx");
+    c->graph_mode = enabled != 0;
+    if (!c->graph_mode) c->drop_graphs();
+    return 0;
+}
+
+int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fgr, void* pha,
+                void* const r_out[4], int seg_pass, void* hip_stream) {
+    if (!c || !c->planned) return fail("rvm_forward: no plan (call rvm_plan)");
+    if (!src || !pha || !r_out || (!seg_pass && !fgr)) return fail("rvm_forward: null buffer");
+    FrameIO io; memset(&io, 0, sizeof io);
+    io.src = src; io.fgr = fgr; io.pha = pha; io.seg = seg_pass ? 1 : 0;
+    for (int i = 0; i < 4; ++i) {
+        io.r_in[i] = r_in ? r_in[i] : nullptr;
+        io.r_out[i] = r_out[i];
+        if (!io.r_out[i]) return fail("rvm_forward: null r_out");
+        if (io.r_out[i] == io.r_in[i]) return fail("rvm_forward: r_out must not alias r_in");
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!c->graph_mode) {
+        for (auto& f : c->launches) f(st, io);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    for (auto& g : c->graphs)
+        if (g.key == io) { HIPCHK(hipGraphLaunch(g.exec, st)); return 0; }
+    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    for (auto& f : c->launches) f(c->cap_stream, io);
+    HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    c->graphs.push_back({io, exec});
+    HIPCHK(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+int rvm_debug_tap(rvm_ctx* c, const char* name, float* out, int64_t cap, int64_t shape[4]) {
+    if (!c || !c->planned || !name) return fail("rvm_debug_tap: no plan");
+    auto it = c->taps.find(name);
+    if (it == c->taps.end()) return fail(std::string("rvm_debug_tap: unknown tap ") + name);
+    const Tap& t = it->second;
+    shape[0] = t.B; shape[1] = t.C; shape[2] = t.H; shape[3] = t.W;
+    const int64_t n = (int64_t)t.B * t.C * t.H * t.W;
+    if (!out) return 0;
+    if (cap < n) return fail("rvm_debug_tap: output too small");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t es = t.is_float ? 4 : c->esize();
+    const size_t pixels = (size_t)t.B * t.H * t.W;
+    std::vector<char> raw(pixels * t.Cs * es);
+    HIPCHK(hipMemcpy(raw.data(), t.p, raw.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < t.B; ++b)
+        for (int y = 0; y < t.H; ++y)
+            for (int x = 0; x < t.W; ++x) {
+                const size_t pix = ((size_t)b * t.H + y) * t.W + x;
+                for (int ch = 0; ch < t.C; ++ch) {
+                    float v = es == 4 ? ((const float*)raw.data())[pix * t.Cs + ch] : (float)((const f16*)raw.data())[pix * t.Cs + ch];
+                    out[(((size_t)b * t.C + ch) * t.H + y) * t.W + x] = v;
+                }
+            }
+    return 0;
+}
+
+}  // extern "C"

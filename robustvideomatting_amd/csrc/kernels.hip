@@ -1,0 +1,826 @@
+// Hand-written CDNA4 (gfx950) kernels for the RVM per-frame inference path.
+//
+// Layout convention: every internal activation is NHWC ("pixels x channels") so that a
+// pixel's channels are contiguous - the K dimension of the MFMA implicit GEMMs - and the
+// 64-lane fragment loads are 16-byte vectors.  Matrix work uses
+//   v_mfma_f32_16x16x32_f16   (fp16 mode, fp32 accumulate)
+//   v_mfma_f32_16x16x4_f32    (fp32 mode, exact fp32 fma chain)
+// with the WEIGHTS as the MFMA A operand (rows = output channels) and the PIXELS as the B
+// operand (columns = pixels), so lane l of the result holds 4 consecutive output channels
+// (l>>4)*4.. of pixel (l&15): one 8/16-byte NHWC store per lane per tile.
+//
+// Reference arithmetic each kernel replaces is cited at the kernel (paths under
+// /root/reference).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+struct F8 { f32x4 lo, hi; };
+
+__device__ __forceinline__ f32x4 ld4f(const f16* p) { return __builtin_convertvector(*(const f16x4*)p, f32x4); }
+__device__ __forceinline__ f32x4 ld4f(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ void st4f(f16* p, f32x4 v) { *(f16x4*)p = __builtin_convertvector(v, f16x4); }
+__device__ __forceinline__ void st4f(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ F8 ld8f(const f16* p) {
+    f16x8 v = *(const f16x8*)p; F8 r;
+    r.lo = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    r.hi = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    return r;
+}
+__device__ __forceinline__ F8 ld8f(const float* p) { F8 r; r.lo = *(const f32x4*)p; r.hi = *(const f32x4*)(p + 4); return r; }
+__device__ __forceinline__ void st8f(f16* p, F8 v) {
+    f16x8 o = {(f16)v.lo[0], (f16)v.lo[1], (f16)v.lo[2], (f16)v.lo[3], (f16)v.hi[0], (f16)v.hi[1], (f16)v.hi[2], (f16)v.hi[3]};
+    *(f16x8*)p = o;
+}
+__device__ __forceinline__ void st8f(float* p, F8 v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
+
+// MFMA operand fragments: 8 K-elements per lane.
+template <typename T> struct Frag;
+template <> struct Frag<f16> {
+    f16x8 v;
+    __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
+    __device__ __forceinline__ void zero() { v = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    __device__ __forceinline__ void scale(const f16* s) { v = v * *(const f16x8*)s; }
+};
+template <> struct Frag<float> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ void load(const float* p) { lo = *(const f32x4*)p; hi = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void zero() { lo = f32x4{0, 0, 0, 0}; hi = lo; }
+    __device__ __forceinline__ void scale(const float* s) { lo = lo * *(const f32x4*)s; hi = hi * *(const f32x4*)(s + 4); }
+};
+
+// acc(16 out-channels x 16 pixels) += W(16 x 32) * X(32 x 16)
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<f16>& w, const Frag<f16>& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.v, x.v, acc, 0, 0, 0);
+}
+// fp32: 8 MFMAs of K=4; in MFMA i lane group g=(l>>4) supplies k = 8g+i for BOTH operands, so
+// the 32-wide K step is covered exactly once (the order inside the step is immaterial).
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag<float>& x) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo[i], x.lo[i], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi[i], x.hi[i], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_f(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+        case ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ------------------------------------------------------------------------------------------
+// Pointwise (1x1) conv as an MFMA GEMM, operands straight from L2 into registers.
+// Replaces: torchvision ConvBNActivation 1x1 (expand / project / features[16]) used by
+// model/mobilenetv3.py:39-58, SE rescale (x * scale), residual add, and LR-ASPP aspp1 * aspp2
+// (model/lraspp.py:6-10,18).  BN is folded into w/bias on the host.
+// ------------------------------------------------------------------------------------------
+template <typename T, int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave % WM, wn = wave / WM;
+    const int mt0 = (blockIdx.x * WM + wm) * MW;
+    const int nt0 = (blockIdx.y * WN + wn) * NW;
+    const int n = blockIdx.z;
+    if (mt0 >= a.MT || nt0 >= a.NT) return;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const T* xp[MW];
+    bool pv[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        int pix = (mt0 + mi) * 16 + l15;
+        pv[mi] = (mt0 + mi) < a.MT && pix < a.HW;
+        xp[mi] = (const T*)a.x + ((size_t)n * a.HW + (pv[mi] ? pix : 0)) * a.xs + g * 8;
+    }
+    const T* wp[NW];
+    bool nv[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        nv[ni] = (nt0 + ni) < a.NT;
+        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
+    }
+    const T* sc = a.in_scale ? (const T*)a.in_scale + (size_t)n * a.Cin : nullptr;
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+
+    Frag<T> wf[NW], xf[MW], wn_[NW], xn_[MW];
+    auto load_step = [&](int ks, Frag<T>* wo, Frag<T>* xo) {
+        const int c = ks * 32 + g * 8;
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) wo[ni].load(wp[ni] + (size_t)ks * 512);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            if (pv[mi] && c < a.Cin) {
+                xo[mi].load(xp[mi] + ks * 32);
+                if (sc) xo[mi].scale(sc + c);
+            } else {
+                xo[mi].zero();
+            }
+        }
+    };
+    load_step(0, wf, xf);
+    for (int ks = 0; ks < a.KS; ++ks) {
+        if (ks + 1 < a.KS) load_step(ks + 1, wn_, xn_);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) wf[ni] = wn_[ni];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) xf[mi] = xn_[mi];
+    }
+
+    // epilogue: lane holds channels ch..ch+3 of pixel pix
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        if (!nv[ni]) continue;
+        const int ch = (nt0 + ni) * 16 + g * 4;
+        const f32x4 bias = *(const f32x4*)(a.bias + ch);
+        f32x4 osc = f32x4{1, 1, 1, 1};
+        if (a.out_scale && ch < a.Cout) osc = *(const f32x4*)(a.out_scale + (size_t)n * a.oss + ch);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int pix = (mt0 + mi) * 16 + l15;
+            f32x4 v = acc[mi][ni] + bias;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+            const bool ok = pv[mi] && ch < a.Cout;
+            if (ok) {
+                if (a.res) v += ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + ch);
+                v *= osc;
+                st4f((T*)a.y + ((size_t)n * a.HW + pix) * a.ys + ch, v);
+            }
+            if (a.pool) {
+                f32x4 s = ok ? v : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], m);
+                }
+                if (l15 == 0 && (mt0 + mi) < a.MT)
+                    *(f32x4*)(a.pool + ((size_t)n * a.MT + mt0 + mi) * (a.NT * 16) + ch) = s;
+            }
+        }
+    }
+}
+
+template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_gemm<T, 2, 1, 4, 1>), dim3(cdiv(a.MT, 8), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 2, 2>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+    }
+}
+template void launch_pw<f16>(const PwArgs&, int, int, hipStream_t);
+template void launch_pw<float>(const PwArgs&, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Depthwise k x k conv (+folded BN, activation, optional squeeze-excite partial sums).
+// Replaces torchvision InvertedResidual's depthwise ConvBNActivation and the avg-pool half
+// of SqueezeExcitation (mobilenetv3.py:39-58).  Block = (C/8 channel groups) x PY pixels;
+// a thread keeps one 8-channel group, so SE sums reduce deterministically through LDS.
+// ------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void dw_conv(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int cg = threadIdx.x, py = threadIdx.y, PY = blockDim.y, n = blockIdx.y;
+    const int c = cg * 8;
+    const int npix = a.Ho * a.Wo;
+    const int pbeg = blockIdx.x * a.ppb;
+    const int pend = min(pbeg + a.ppb, npix);
+    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.C;
+    T* yb = (T*)a.y + (size_t)n * npix * a.C;
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    f32x4 ps0 = f32x4{0, 0, 0, 0}, ps1 = ps0;
+    for (int p = pbeg + py; p < pend; p += PY) {
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        f32x4 a0 = b0, a1 = b1;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky * a.dil;
+            if (iy < 0 || iy >= a.Hi) continue;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * a.stride - a.pad + kx * a.dil;
+                if (ix < 0 || ix >= a.Wi) continue;
+                F8 v = ld8f(xb + ((size_t)iy * a.Wi + ix) * a.C + c);
+                const float* wp = a.w + (ky * K + kx) * a.C + c;
+                a0 += v.lo * *(const f32x4*)wp;
+                a1 += v.hi * *(const f32x4*)(wp + 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = act_f(a0[r], a.act); a1[r] = act_f(a1[r], a.act); }
+        F8 o; o.lo = a0; o.hi = a1;
+        st8f(yb + (size_t)p * a.C + c, o);
+        ps0 += a0; ps1 += a1;
+    }
+    if (a.pool) {
+        *(f32x4*)(red + py * a.C + c) = ps0;
+        *(f32x4*)(red + py * a.C + c + 4) = ps1;
+        __syncthreads();
+        if (py == 0) {
+            for (int q = 1; q < PY; ++q) {
+                ps0 += *(const f32x4*)(red + q * a.C + c);
+                ps1 += *(const f32x4*)(red + q * a.C + c + 4);
+            }
+            float* o = a.pool + ((size_t)n * a.nblk + blockIdx.x) * a.C + c;
+            *(f32x4*)o = ps0;
+            *(f32x4*)(o + 4) = ps1;
+        }
+    }
+}
+
+template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s) {
+    const int CG = a.C / 8;
+    int PY = 256 / CG; if (PY < 1) PY = 1;
+    dim3 block(CG, PY), grid(a.nblk, N);
+    size_t lds = a.pool ? (size_t)PY * a.C * sizeof(float) : 0;
+    if (K == 3) hipLaunchKernelGGL((dw_conv<T, 3>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((dw_conv<T, 5>), grid, block, lds, s, a);
+}
+template void launch_dw<f16>(const DwArgs&, int, int, hipStream_t);
+template void launch_dw<float>(const DwArgs&, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Dense layer on a pooled vector: SE fc1 (+ReLU), fc2 (+hardsigmoid) and the LR-ASPP gate
+// (global mean -> 1x1 conv -> sigmoid, lraspp.py:11-15).  The input vector is first reduced
+// from per-block partial sums (fixed order => deterministic).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_act(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < a.I; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < a.nparts; ++p) s += a.xin[((size_t)n * a.nparts + p) * a.part_stride + i];
+        xs[i] = s * a.xscale;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = 0; k < a.opw; ++k) {
+        const int o = (blockIdx.x * 4 + wave) * a.opw + k;
+        if (o >= a.O) break;
+        const T* wr = (const T*)a.w + (size_t)o * a.I;
+        float s = 0.f;
+        for (int i = lane * 8; i < a.I; i += 512) {
+            F8 wv = ld8f(wr + i);
+            const f32x4 x0 = *(const f32x4*)(xs + i), x1 = *(const f32x4*)(xs + i + 4);
+            s += wv.lo[0] * x0[0] + wv.lo[1] * x0[1] + wv.lo[2] * x0[2] + wv.lo[3] * x0[3]
+               + wv.hi[0] * x1[0] + wv.hi[1] * x1[1] + wv.hi[2] * x1[2] + wv.hi[3] * x1[3];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) {
+            if (a.bias) s += a.bias[o];
+            s = act_f(s, a.act);
+            if (a.y_is_T) ((T*)a.y)[(size_t)n * a.O + o] = (T)s;
+            else ((float*)a.y)[(size_t)n * a.O + o] = s;
+        }
+    }
+}
+template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) {
+    const int opb = 4 * a.opw;
+    hipLaunchKernelGGL((gemv_act<T>), dim3((a.O + opb - 1) / opb, N), dim3(256), (size_t)a.I * sizeof(float), s, a);
+}
+template void launch_gemv<f16>(const GemvArgs&, int, hipStream_t);
+template void launch_gemv<float>(const GemvArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// 3x3 conv (pad 1) as an LDS-tiled implicit GEMM over up to four concatenated sources, any of
+// which may be a x2 bilinear upsample computed while the halo patch is staged.
+// Replaces, in model/decoder.py: UpsamplingBlock upsample+crop+cat+conv+BN+ReLU (:82-86),
+// OutputBlock (:127-131) and both ConvGRU convolutions with their sigmoid / tanh / state
+// blend epilogues (:168-172).  K index = tap * Cpad + channel; each 8-channel group of a K
+// step may sit on a different tap.
+// ------------------------------------------------------------------------------------------
+template <typename T> size_t conv3_lds_bytes(int MW, int Cpad) {
+    return (size_t)(4 * MW + 2) * 18 * (Cpad + Tr<T>::kLdsPad) * sizeof(T);
+}
+template size_t conv3_lds_bytes<f16>(int, int);
+template size_t conv3_lds_bytes<float>(int, int);
+
+template <typename T, int MW, int NW>
+__global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* patch = (T*)smem;
+    constexpr int TH = 4 * MW, PH = TH + 2, PW = 18;
+    const int CSL = a.Cpad + Tr<T>::kLdsPad;
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * 16, n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    // ---- stage the (TH+2) x 18 halo patch of the concatenated input ----
+    {
+        const int QN = a.Cpad >> 2;
+        const int QL = 1 << a.ql_log2;
+        const int ql = tid & (QL - 1), pl = tid >> a.ql_log2, pstep = 256 >> a.ql_log2;
+        for (int pp = pl; pp < PH * PW; pp += pstep) {
+            const int py = pp / PW, px = pp - py * PW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
+            float sy = fmaxf(gy * 0.5f - 0.25f, 0.f), sx = fmaxf(gx * 0.5f - 0.25f, 0.f);
+            const int iy0 = (int)sy, ix0 = (int)sx;
+            const float ly = sy - iy0, lx = sx - ix0;
+            for (int q = ql; q < QN; q += QL) {
+                int cc = q * 4, s = 0;
+                while (s < a.nsrc && cc >= a.src[s].C) { cc -= a.src[s].C; ++s; }
+                f32x4 v = f32x4{0, 0, 0, 0};
+                if (inb && s < a.nsrc && a.src[s].p) {
+                    const ConvSrc& S = a.src[s];
+                    const T* p = (const T*)S.p;
+                    if (!S.up) {
+                        v = ld4f(p + (((size_t)n * H + gy) * W + gx) * S.Cs + cc);
+                    } else {
+                        const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
+                        const T* b = p + (size_t)n * S.Hs * S.Ws * S.Cs + cc;
+                        f32x4 v00 = ld4f(b + ((size_t)iy0 * S.Ws + ix0) * S.Cs);
+                        f32x4 v01 = ld4f(b + ((size_t)iy0 * S.Ws + ix1) * S.Cs);
+                        f32x4 v10 = ld4f(b + ((size_t)iy1 * S.Ws + ix0) * S.Cs);
+                        f32x4 v11 = ld4f(b + ((size_t)iy1 * S.Ws + ix1) * S.Cs);
+                        v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                    }
+                }
+                st4f(patch + pp * CSL + q * 4, v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- implicit GEMM ----
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.y * NW;
+    const int NQ8 = a.Cpad >> 3;
+    int tap = 0, c8 = g;
+    while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+
+    const T* wp[NW];
+    bool nv[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        nv[ni] = (nt0 + ni) < a.NT;
+        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
+    }
+    Frag<T> wf[NW], wn_[NW], xf[MW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) wf[ni].load(wp[ni]);
+    for (int ks = 0; ks < a.KS; ++ks) {
+        if (ks + 1 < a.KS) {
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) wn_[ni].load(wp[ni] + (size_t)(ks + 1) * 512);
+        }
+        const int tp = min(tap, 8);                 // K tail: weights are zero there, keep the read in-bounds
+        const int dy = (tp * 11) >> 5, dx = tp - dy * 3;
+        const T* pb = patch + ((wave + dy) * PW + l15 + dx) * CSL + c8 * 8;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi) * PW * CSL);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) wf[ni] = wn_[ni];
+        c8 += 4;
+        while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+    }
+
+    // ---- epilogue ----
+    const int gx = x0 + l15;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int gy = y0 + wave + 4 * mi;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = ((size_t)n * H + gy) * W + gx;
+        if (a.epi == EPI_RELU) {
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) {
+                const int ch = (nt0 + ni) * 16 + g * 4;
+                if (!nv[ni] || ch >= a.Cout) continue;
+                f32x4 v = acc[mi][ni] + *(const f32x4*)(a.bias + ch);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                st4f((T*)a.y + pix * a.ys + ch, v);
+            }
+        } else if (a.epi == EPI_GRU_IH) {
+            // tiles come in (r, z) pairs: packed tile 2j = r[16j..], 2j+1 = z[16j..]  (decoder.py:169)
+            if constexpr (NW >= 2) {
+#pragma unroll
+                for (int ni = 0; ni + 1 < NW; ni += 2) {
+                    const int t = nt0 + ni;
+                    const int c = (t >> 1) * 16 + g * 4;
+                    if (!nv[ni] || c >= a.hC) continue;
+                    f32x4 rv = acc[mi][ni] + *(const f32x4*)(a.bias + t * 16 + g * 4);
+                    f32x4 zv = acc[mi][ni + 1] + *(const f32x4*)(a.bias + (t + 1) * 16 + g * 4);
+                    f32x4 h = f32x4{0, 0, 0, 0};
+                    if (a.hprev) h = ld4f((const T*)a.hprev + pix * a.hC + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { rv[r] = sigmoid_f(rv[r]) * h[r]; zv[r] = sigmoid_f(zv[r]); }
+                    st4f((T*)a.rh + pix * a.hC + c, rv);
+                    *(f32x4*)(a.z + pix * a.hC + c) = zv;
+                }
+            }
+        } else {
+            // candidate + blend: h' = (1-z) h + z tanh(.)   (decoder.py:170-171)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) {
+                const int c = (nt0 + ni) * 16 + g * 4;
+                if (!nv[ni] || c >= a.hC) continue;
+                f32x4 cv = acc[mi][ni] + *(const f32x4*)(a.bias + c);
+                f32x4 h = f32x4{0, 0, 0, 0};
+                if (a.hprev) h = ld4f((const T*)a.hprev + pix * a.hC + c);
+                const f32x4 z = *(const f32x4*)(a.z + pix * a.hC + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
+                st4f((T*)a.hout + pix * a.hC + c, cv);
+            }
+        }
+    }
+}
+
+template <typename T, int MW, int NW>
+static void launch_conv3_t(const ConvArgs& a, int N, hipStream_t s) {
+    const int TH = 4 * MW;
+    const int tiles_y = (a.H + TH - 1) / TH;
+    dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
+    hipLaunchKernelGGL((conv3x3<T, MW, NW>), grid, dim3(256), conv3_lds_bytes<T>(MW, a.Cpad), s, a);
+}
+template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, hipStream_t s) {
+    if (MW == 4 && NW == 1) launch_conv3_t<T, 4, 1>(a, N, s);
+    else if (MW == 2 && NW == 2) launch_conv3_t<T, 2, 2>(a, N, s);
+    else if (MW == 2 && NW == 1) launch_conv3_t<T, 2, 1>(a, N, s);
+    else if (MW == 1 && NW == 2) launch_conv3_t<T, 1, 2>(a, N, s);
+    else launch_conv3_t<T, 1, 1>(a, N, s);
+}
+template void launch_conv3<f16>(const ConvArgs&, int, int, int, hipStream_t);
+template void launch_conv3<float>(const ConvArgs&, int, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Stem: ImageNet normalise + 3x3 stride-2 conv 3->16 + BN + hardswish
+// (mobilenetv3.py:37,39; torchvision features[0]).  Normalisation is applied to in-bounds
+// pixels only, so the conv's zero padding pads the *normalised* image like the reference.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv(StemArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (p >= a.Ho * a.Wo) return;
+    const int oy = p / a.Wo, ox = p - oy * a.Wo;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = a.bias[o];
+    const T* xb = (const T*)a.s0 + (size_t)n * a.Hi * a.Wi * 4;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+        if (iy < 0 || iy >= a.Hi) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (ix < 0 || ix >= a.Wi) continue;
+            f32x4 v = ld4f(xb + ((size_t)iy * a.Wi + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xn = (v[c] - a.mean[c]) / a.std_[c];
+                const float* w = a.w + ((ky * 3 + kx) * 3 + c) * 16;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) acc[o] += xn * w[o];
+            }
+        }
+    }
+    T* yb = (T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_f(acc[q * 4 + r], ACT_HSWISH);
+        st4f(yb + q * 4, v);
+    }
+}
+template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s) {
+    hipLaunchKernelGGL((stem_conv<T>), dim3((a.Ho * a.Wo + 255) / 256, N), dim3(256), 0, s, a);
+}
+template void launch_stem<f16>(const StemArgs&, int, hipStream_t);
+template void launch_stem<float>(const StemArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Downsample src (NCHW, full res) -> s0 (NHWC4: r,g,b,gray) with scale-factor-driven
+// bilinear coordinates (model/model.py:80-81: align_corners=False,
+// recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void downsample(DownArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (p >= a.h * a.w) return;
+    const int oy = p / a.w, ox = p - oy * a.w;
+    float sy = a.scale_y * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = a.scale_x * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    int y0 = (int)sy, x0 = (int)sx;
+    if (y0 > a.H - 1) y0 = a.H - 1;
+    if (x0 > a.W - 1) x0 = a.W - 1;
+    const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
+    const float ly = sy - y0, lx = sx - x0;
+    const T* sp = (const T*)a.src + (size_t)n * 3 * a.H * a.W;
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T* pl = sp + (size_t)c * a.H * a.W;
+        const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
+        const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
+        o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        o[c] = (float)(T)o[c];
+    }
+    o[3] = (o[0] + o[1] + o[2]) / 3.f;
+    st4f((T*)a.s0 + ((size_t)n * a.h * a.w + p) * 4, o);
+}
+template <typename T> void launch_down(const DownArgs& a, int N, hipStream_t s) {
+    hipLaunchKernelGGL((downsample<T>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
+}
+template void launch_down<f16>(const DownArgs&, int, hipStream_t);
+template void launch_down<float>(const DownArgs&, int, hipStream_t);
+
+// 2x2 stride-2 average pool, ceil_mode, count_include_pad=False (decoder.py:33) on NHWC4.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2(PoolArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (p >= a.Ho * a.Wo) return;
+    const int oy = p / a.Wo, ox = p - oy * a.Wo;
+    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * 4;
+    f32x4 s = f32x4{0, 0, 0, 0};
+    int cnt = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+            if (iy < a.Hi && ix < a.Wi) { s += ld4f(xb + ((size_t)iy * a.Wi + ix) * 4); ++cnt; }
+        }
+    s = s / (float)cnt;
+    st4f((T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 4, s);
+}
+template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s) {
+    hipLaunchKernelGGL((avgpool2<T>), dim3((a.Ho * a.Wo + 255) / 256, N), dim3(256), 0, s, a);
+}
+template void launch_pool<f16>(const PoolArgs&, int, hipStream_t);
+template void launch_pool<float>(const PoolArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Refiner, low-res half: project_mat 1x1 (model.py:62) + guided-filter statistics with the
+// 3x3 box filter on LDS + the 1x1 MLP (deep_guided_filter.py:26-35) or cov/(var+eps)
+// (fast_guided_filter.py:51-56).  Emits A|b as [h][w][8] fp32.  All arithmetic in fp32.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dgf_lowres(DgfLowArgs a) {
+    __shared__ f32x4 sx[18 * 18], sy[18 * 18];
+    const DgfWeights& wt = *a.wt;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const T* hid = (const T*)a.hid + (size_t)n * a.h * a.w * 16;
+    const T* s0 = (const T*)a.s0 + (size_t)n * a.h * a.w * 4;
+    for (int pp = threadIdx.x; pp < 324; pp += 256) {
+        const int py = pp / 18, px = pp - py * 18;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        f32x4 xv = f32x4{0, 0, 0, 0}, yv = xv;
+        if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) {
+            const size_t pix = (size_t)gy * a.w + gx;
+            xv = ld4f(s0 + pix * 4);
+            xv[3] = (xv[0] + xv[1] + xv[2]) / 3.f;
+            F8 h0 = ld8f(hid + pix * 16), h1 = ld8f(hid + pix * 16 + 8);
+            float hv[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hv[k] = h0.lo[k]; hv[4 + k] = h0.hi[k]; hv[8 + k] = h1.lo[k]; hv[12 + k] = h1.hi[k]; }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = wt.proj_b[o];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s += wt.proj_w[o][k] * hv[k];
+                yv[o] = s;
+            }
+        }
+        sx[pp] = xv; sy[pp] = yv;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int gy = y0 + ly, gx = x0 + lx;
+    if (gy >= a.h || gx >= a.w) return;
+    f32x4 mx = f32x4{0, 0, 0, 0}, my = mx, exy = mx, exx = mx;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int pp = (ly + t / 3) * 18 + lx + t % 3;
+        const f32x4 xv = sx[pp], yv = sy[pp];
+        f32x4 bw;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bw[c] = wt.box[c][t];
+        mx += bw * xv; my += bw * yv; exy += bw * (xv * yv); exx += bw * (xv * xv);
+    }
+    const f32x4 cov = exy - mx * my, var = exx - mx * mx;
+    f32x4 A;
+    if (a.fast) {
+        A = cov / (var + 1e-5f);
+    } else {
+        const size_t pix = (size_t)gy * a.w + gx;
+        float in[24];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { in[k] = cov[k]; in[4 + k] = var[k]; }
+        F8 h0 = ld8f(hid + pix * 16), h1 = ld8f(hid + pix * 16 + 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { in[8 + k] = h0.lo[k]; in[12 + k] = h0.hi[k]; in[16 + k] = h1.lo[k]; in[20 + k] = h1.hi[k]; }
+        float t1[16], t2[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float s = wt.b1[o];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) s += wt.w1[o][k] * in[k];
+            t1[o] = fmaxf(s, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float s = wt.b2[o];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += wt.w2[o][k] * t1[k];
+            t2[o] = fmaxf(s, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float s = wt.b3[o];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += wt.w3[o][k] * t2[k];
+            A[o] = s;
+        }
+    }
+    const f32x4 b = my - A * mx;
+    float* o = a.ab + (((size_t)n * a.h + gy) * a.w + gx) * 8;
+    *(f32x4*)o = A;
+    *(f32x4*)(o + 4) = b;
+}
+template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s) {
+    const int tiles_y = (a.h + 15) / 16;
+    hipLaunchKernelGGL((dgf_lowres<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
+}
+template void launch_dgf_low<f16>(const DgfLowArgs&, int, hipStream_t);
+template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Refiner, full-res half: bilinear-upsample A|b (size-driven coords, deep_guided_filter.py:
+// 37-39), out = A*[src,gray]+b (:41), fgr = clamp(out+src), pha = clamp(out) (model.py:65-67).
+// One pass: src read once, fgr/pha written once; a thread owns 8 consecutive x.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    const int y = blockIdx.y, n = blockIdx.z;
+    if (x0 >= a.W) return;
+    float sy = a.scale_y * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    int iy0 = (int)sy; if (iy0 > a.h - 1) iy0 = a.h - 1;
+    const int iy1 = iy0 + (iy0 < a.h - 1);
+    const float ly = sy - iy0;
+    const float* r0 = a.ab + ((size_t)n * a.h + iy0) * a.w * 8;
+    const float* r1 = a.ab + ((size_t)n * a.h + iy1) * a.w * 8;
+    const size_t plane = (size_t)a.H * a.W;
+    const T* sp = (const T*)a.src + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
+    T* fp = (T*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
+    T* pp = (T*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
+    const bool full = (x0 + 8 <= a.W) && ((a.W & 7) == 0);
+    float s[3][8];
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            F8 v = ld8f(sp + c * plane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[c][j] = v.lo[j]; s[c][4 + j] = v.hi[j]; }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[c][j] = (x0 + j < a.W) ? (float)sp[c * plane + j] : 0.f;
+    }
+    float of[3][8], op[8];
+    int c0 = -1, c1 = -1;
+    f32x4 A0, B0, A1, B1;
+    A0 = B0 = A1 = B1 = f32x4{0, 0, 0, 0};
+    auto col = [&](int i, f32x4& A, f32x4& B) {
+        const f32x4 ta = *(const f32x4*)(r0 + (size_t)i * 8), tb = *(const f32x4*)(r0 + (size_t)i * 8 + 4);
+        const f32x4 ba = *(const f32x4*)(r1 + (size_t)i * 8), bb = *(const f32x4*)(r1 + (size_t)i * 8 + 4);
+        A = (1.f - ly) * ta + ly * ba;
+        B = (1.f - ly) * tb + ly * bb;
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float sx = a.scale_x * (x0 + j + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        int ix0 = (int)sx; if (ix0 > a.w - 1) ix0 = a.w - 1;
+        const int ix1 = ix0 + (ix0 < a.w - 1);
+        const float lx = sx - ix0;
+        if (ix0 != c0) {
+            if (ix0 == c1) { A0 = A1; B0 = B1; } else col(ix0, A0, B0);
+            c0 = ix0;
+        }
+        if (ix1 != c1) {
+            if (ix1 == c0) { A1 = A0; B1 = B0; } else col(ix1, A1, B1);
+            c1 = ix1;
+        }
+        const f32x4 A = (1.f - lx) * A0 + lx * A1, B = (1.f - lx) * B0 + lx * B1;
+        const float gray = (s[0][j] + s[1][j] + s[2][j]) / 3.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) of[c][j] = fminf(fmaxf(A[c] * s[c][j] + B[c] + s[c][j], 0.f), 1.f);
+        op[j] = fminf(fmaxf(A[3] * gray + B[3], 0.f), 1.f);
+    }
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            F8 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v.lo[j] = of[c][j]; v.hi[j] = of[c][4 + j]; }
+            st8f(fp + c * plane, v);
+        }
+        F8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v.lo[j] = op[j]; v.hi[j] = op[4 + j]; }
+        st8f(pp, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (x0 + j < a.W) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fp[c * plane + j] = (T)of[c][j];
+                pp[j] = (T)op[j];
+            }
+        }
+    }
+}
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, hipStream_t s) {
+    const int groups = (a.W + 7) / 8;
+    hipLaunchKernelGGL((dgf_apply<T>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
+}
+template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, hipStream_t);
+template void launch_dgf_apply<float>(const DgfApplyArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// downsample_ratio == 1 tail (no refiner): project_mat + residual + clamp (model.py:62,65-67)
+// or project_seg (model.py:70) when seg != 0 (written to `pha`, no clamp).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    const int HW = a.H * a.W;
+    if (p >= HW) return;
+    const DgfWeights& wt = *a.wt;
+    const T* hp = (const T*)a.hid + ((size_t)n * HW + p) * 16;
+    F8 h0 = ld8f(hp), h1 = ld8f(hp + 8);
+    float hv[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hv[k] = h0.lo[k]; hv[4 + k] = h0.hi[k]; hv[8 + k] = h1.lo[k]; hv[12 + k] = h1.hi[k]; }
+    if (a.seg) {
+        float s = wt.seg_b;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += wt.seg_w[k] * hv[k];
+        ((T*)a.pha)[(size_t)n * HW + p] = (T)s;
+        return;
+    }
+    float y[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float s = wt.proj_b[o];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += wt.proj_w[o][k] * hv[k];
+        y[o] = s;
+    }
+    const T* sp = (const T*)a.src + (size_t)n * 3 * HW + p;
+    T* fp = (T*)a.fgr + (size_t)n * 3 * HW + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fp[(size_t)c * HW] = (T)fminf(fmaxf(y[c] + (float)sp[(size_t)c * HW], 0.f), 1.f);
+    ((T*)a.pha)[(size_t)n * HW + p] = (T)fminf(fmaxf(y[3], 0.f), 1.f);
+}
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, hipStream_t s) {
+    hipLaunchKernelGGL((proj_out<T>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
+}
+template void launch_proj_out<f16>(const ProjOutArgs&, int, hipStream_t);
+template void launch_proj_out<float>(const ProjOutArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int MW, int NW> static void conv3_attr() {
+    (void)hipFuncSetAttribute((const void*)conv3x3<T, MW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+void kernels_init() {
+    conv3_attr<f16, 4, 1>(); conv3_attr<f16, 2, 2>(); conv3_attr<f16, 2, 1>(); conv3_attr<f16, 1, 2>(); conv3_attr<f16, 1, 1>();
+    conv3_attr<float, 4, 1>(); conv3_attr<float, 2, 2>(); conv3_attr<float, 2, 1>(); conv3_attr<float, 1, 2>(); conv3_attr<float, 1, 1>();
+}

@@ -1,0 +1,265 @@
+"""Drop-in ``MattingNetwork`` for MI355X.
+
+Same constructor, ``forward`` signature, ``state_dict`` keys and recurrent-state
+contract as the reference class (/root/reference/model/model.py:14-71), so
+
+    from robustvideomatting_amd import MattingNetwork      # instead of: from model import MattingNetwork
+
+is the only edit ``inference.py`` / ``hubconf.py`` style callers make.  The
+module only *holds* the parameters; all arithmetic happens in
+librvm_mi355x.so (hand-written gfx950 kernels) reached through the C ABI in
+include/rvm_mi355x.h.  There is no PyTorch/CPU fallback: calling it with CPU
+tensors, or without the native library, raises.
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import native, spec
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class _Node(nn.Module):
+    """Anonymous container; lets ``model.backbone.features[3].block[0][1].weight`` work."""
+
+    def __getitem__(self, idx):
+        return getattr(self, str(idx))
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container - compute happens in MattingNetwork.forward")
+
+
+def _default_init(name, shape, gen, bn_prefixes):
+    """Random init in the spirit of the reference's (torchvision kaiming_normal_ fan_out for
+    the encoder, nn.Conv2d defaults elsewhere, identity BatchNorm)."""
+    prefix, leaf = name.rsplit(".", 1)
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.long)
+    if leaf == "running_mean":
+        return torch.zeros(shape)
+    if leaf == "running_var":
+        return torch.ones(shape)
+    if name == "refiner.box_filter.weight":
+        return torch.full(shape, 1.0 / 9.0)                       # deep_guided_filter.py:13
+    if prefix in bn_prefixes:
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+    if len(shape) == 1:                                           # conv bias
+        return (torch.rand(shape, generator=gen) * 2 - 1) * 0.05
+    fan_in = shape[1] * shape[2] * shape[3]
+    if name.startswith("backbone."):
+        fan_out = shape[0] * shape[2] * shape[3]
+        return torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_out)
+    bound = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+class MattingNetwork(nn.Module):
+    def __init__(self,
+                 variant: str = 'mobilenetv3',
+                 refiner: str = 'deep_guided_filter',
+                 pretrained_backbone: bool = False):
+        super().__init__()
+        assert variant in ['mobilenetv3', 'resnet50']
+        assert refiner in ['fast_guided_filter', 'deep_guided_filter']
+        if pretrained_backbone:
+            raise RuntimeError("pretrained_backbone=True needs a network fetch "
+                               "(reference mobilenetv3.py:29-31); load a state_dict instead")
+        self.variant = variant
+        self.refiner_kind = refiner
+        shapes = spec.param_shapes(variant, refiner)
+        bn_prefixes = {n[:-len(".running_mean")] for n in shapes if n.endswith(".running_mean")}
+        gen = torch.Generator().manual_seed(0)
+        self._names = list(shapes.keys())
+        for name, shape in shapes.items():
+            value = _default_init(name, shape, gen, bn_prefixes)
+            node = self
+            parts = name.split(".")
+            for part in parts[:-1]:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            if parts[-1] in _BUFFER_LEAVES:
+                node.register_buffer(parts[-1], value)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+        self._ctx = None            # native.Context
+        self._ctx_key = None        # (device index, dtype)
+        self._dirty = True          # parameters changed since the last upload
+        self._graph = False
+        self._ring = {}             # plan key -> ring of static output/state buffers (graph mode)
+        self._ring_pos = 0
+
+    # ---- bookkeeping: any .to()/.half()/.cuda()/load_state_dict invalidates the packed weights
+    def _apply(self, fn, *args, **kwargs):
+        self._dirty = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._dirty = True
+        return super().load_state_dict(*args, **kwargs)
+
+    def refresh(self):
+        """Call after modifying parameters in place."""
+        self._dirty = True
+
+    def enable_graph(self, on: bool = True):
+        """Replay the per-frame schedule as a HIP graph.  Outputs and states then live in a
+        ring of two static buffer sets per shape: a returned tensor is overwritten by the
+        second-next call (inference.py consumes them immediately, reference inference.py:129-141)."""
+        self._graph = bool(on)
+        if self._ctx is not None:
+            self._ctx.set_graph_mode(self._graph)
+        return self
+
+    def _native(self, device, dtype):
+        if dtype == torch.float32:
+            code = native.DTYPE_F32
+        elif dtype == torch.float16:
+            code = native.DTYPE_F16
+        else:
+            raise RuntimeError("MattingNetwork (MI355X): unsupported dtype %s (float32 / float16)" % dtype)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), code)
+        if self._ctx is None or self._ctx_key != key:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = native.Context(self.variant, self.refiner_kind, code, key[0])
+            self._ctx.set_graph_mode(self._graph)
+            self._ctx_key = key
+            self._dirty = True
+            self._ring = {}
+        if self._dirty:
+            sd = self.state_dict()
+            for name, shape in self._ctx.param_specs():
+                if len(shape) == 0:
+                    continue
+                t = sd[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+                if tuple(t.shape) != shape:
+                    raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+                self._ctx.set_param(name, t)
+            self._ctx.finalize()
+            self._dirty = False
+            self._ring = {}
+        return self._ctx
+
+    # ---- the hot path
+    def forward(self,
+                src: Tensor,
+                trimap: Optional[Tensor] = None,
+                r1: Optional[Tensor] = None,
+                r2: Optional[Tensor] = None,
+                r3: Optional[Tensor] = None,
+                r4: Optional[Tensor] = None,
+                downsample_ratio: float = 1,
+                segmentation_pass: bool = False):
+        # Upstream RVM callers use forward(src, r1, r2, r3, r4, downsample_ratio); this fork
+        # inserted `trimap` (reference model/model.py:42, never read).  Recognise the upstream
+        # positional form so both keep working.
+        if isinstance(r4, (int, float)) and not isinstance(r4, bool):
+            trimap, r1, r2, r3, r4, downsample_ratio = None, trimap, r1, r2, r3, float(r4)
+        elif (r4 is None and isinstance(trimap, Tensor) and trimap.ndim == 4 and src.ndim >= 4
+              and trimap.shape[1] == spec.state_channels(self.variant)[0] and trimap.shape[1] != src.shape[-3]):
+            trimap, r1, r2, r3, r4 = None, trimap, r1, r2, r3
+        return self._run(src, [r1, r2, r3, r4], float(downsample_ratio), bool(segmentation_pass))
+
+    def forward_upstream(self, src, r1=None, r2=None, r3=None, r4=None, downsample_ratio: float = 1,
+                         segmentation_pass: bool = False):
+        """Explicit upstream-RVM signature (README.md:184 of the reference)."""
+        return self._run(src, [r1, r2, r3, r4], float(downsample_ratio), bool(segmentation_pass))
+
+    def _run(self, src, rec, ds, seg):
+        if not isinstance(src, Tensor) or src.ndim not in (4, 5) or src.shape[-3] != 3:
+            raise RuntimeError("src must be [B,3,H,W] or [B,T,3,H,W]")
+        if not src.is_cuda:
+            raise RuntimeError("MattingNetwork (MI355X) runs on HIP device tensors only; got a %s tensor. "
+                               "There is no CPU fallback by design." % src.device.type)
+        wdtype = self.project_mat.conv.weight.dtype
+        if src.dtype != wdtype:
+            raise RuntimeError("Input type (%s) and weight type (%s) should be the same" % (src.dtype, wdtype))
+        ctx = self._native(src.device, src.dtype)
+        five = src.ndim == 5
+        if five:
+            B, T = src.shape[:2]
+            frames = src.transpose(0, 1)            # [T,B,3,H,W]
+        else:
+            B, T = src.shape[0], 1
+            frames = src.unsqueeze(0)
+        H, W = src.shape[-2:]
+        ctx.plan(B, H, W, ds)
+        shapes = [ctx.state_shape(l) for l in (1, 2, 3, 4)]
+        dev, dt = src.device, src.dtype
+
+        rec = list(rec)
+        for i, r in enumerate(rec):
+            if r is None:
+                continue
+            if not isinstance(r, Tensor):
+                raise RuntimeError("r%d must be a Tensor or None" % (i + 1))
+            if tuple(r.shape) == (1, 1, 1, 1) and float(r.abs().sum()) == 0.0:
+                rec[i] = None                       # ONNX-style explicit zero state (documentation/inference.md:212)
+                continue
+            if tuple(r.shape) != shapes[i]:
+                raise RuntimeError("Sizes of tensors must match: r%d is %s but this input needs %s "
+                                   "(the recurrent state cannot follow a resolution change)"
+                                   % (i + 1, tuple(r.shape), shapes[i]))
+            if r.device != dev or r.dtype != dt:
+                raise RuntimeError("r%d must be on %s with dtype %s" % (i + 1, dev, dt))
+            rec[i] = r.contiguous(memory_format=torch.channels_last)
+
+        h0, w0 = spec.lowres_size(H, W, ds)
+        oshape0 = (B, 1, h0, w0) if seg else (B, 3, H, W)
+        oshape1 = None if seg else (B, 1, H, W)
+        out0 = torch.empty((T,) + oshape0, device=dev, dtype=dt)
+        out1 = None if seg else torch.empty((T,) + oshape1, device=dev, dtype=dt)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ring = self._static_ring(ctx, shapes, (B, 3, H, W), (B, 1, H, W), dev, dt) if self._graph else None
+        for t in range(T):
+            f = frames[t]
+            if not f.is_contiguous():
+                f = f.contiguous()
+            if ring is not None and not seg:
+                # static buffers => stable pointers => the captured HIP graph can be replayed
+                slot = ring[self._ring_pos]
+                self._ring_pos = (self._ring_pos + 1) % len(ring)
+                new, o0, o1 = slot["r"], slot["fgr"], slot["pha"]
+            else:
+                new = [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
+                o0, o1 = out0[t], (None if seg else out1[t])
+            rin = [r.data_ptr() if r is not None else 0 for r in rec]
+            if seg:
+                ctx.forward(f.data_ptr(), rin, 0, o0.data_ptr(), [n.data_ptr() for n in new], True, stream)
+            else:
+                ctx.forward(f.data_ptr(), rin, o0.data_ptr(), o1.data_ptr(), [n.data_ptr() for n in new], False, stream)
+                if ring is not None:
+                    if T == 1:
+                        out0, out1 = o0.unsqueeze(0), o1.unsqueeze(0)
+                    else:
+                        out0[t].copy_(o0)
+                        out1[t].copy_(o1)
+            rec = new
+        if five:
+            outs = [out0.transpose(0, 1)] if seg else [out0.transpose(0, 1), out1.transpose(0, 1)]
+        else:
+            outs = [out0[0]] if seg else [out0[0], out1[0]]
+        return [*outs, *rec]
+
+    def _static_ring(self, ctx, shapes, fshape, pshape, dev, dt):
+        key = (ctx.plan_key, dev, dt)
+        ring = self._ring.get(key)
+        if ring is None:
+            ring = [dict(r=[torch.zeros(s, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+                            for s in shapes],
+                         fgr=torch.empty(fshape, device=dev, dtype=dt),
+                         pha=torch.empty(pshape, device=dev, dtype=dt)) for _ in range(2)]
+            self._ring = {key: ring}
+            self._ring_pos = 0
+        return ring
+
+    def debug_tap(self, name):
+        """fp32 NCHW copy of an intermediate activation of the last frame (tests only)."""
+        return self._ctx.debug_tap(name)
+
+    def launch_count(self):
+        return self._ctx.launch_count()

@@ -1,0 +1,153 @@
+"""ctypes binding of librvm_mi355x.so (include/rvm_mi355x.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol
+cannot be resolved, importing the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librvm_mi355x.so")
+
+DTYPE_F32, DTYPE_F16 = 0, 1
+VARIANTS = {"mobilenetv3": 0, "resnet50": 1}
+REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
+
+# every symbol include/rvm_mi355x.h declares
+SYMBOLS = [
+    "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
+    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_state_shape", "rvm_forward",
+    "rvm_debug_tap", "rvm_launch_count", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "librvm_mi355x.so not found at %s - build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C robustvideomatting_amd/csrc`"
+            % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cpp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    L.rvm_create.argtypes = [ci, ci, ci, ci, ctypes.POINTER(vp)]
+    L.rvm_create.restype = ci
+    L.rvm_destroy.argtypes = [vp]
+    L.rvm_destroy.restype = None
+    L.rvm_param_count.argtypes = [vp]
+    L.rvm_param_count.restype = ci
+    L.rvm_param_name.argtypes = [vp, ci]
+    L.rvm_param_name.restype = ctypes.c_char_p
+    L.rvm_param_shape.argtypes = [vp, ci, i64p]
+    L.rvm_param_shape.restype = ci
+    L.rvm_set_param.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64]
+    L.rvm_set_param.restype = ci
+    L.rvm_finalize.argtypes = [vp]
+    L.rvm_finalize.restype = ci
+    L.rvm_plan.argtypes = [vp, ci, ci, ci, ctypes.c_double]
+    L.rvm_plan.restype = ci
+    L.rvm_state_shape.argtypes = [vp, ci, i64p]
+    L.rvm_state_shape.restype = ci
+    L.rvm_forward.argtypes = [vp, vp, cpp, vp, vp, cpp, ci, vp]
+    L.rvm_forward.restype = ci
+    L.rvm_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64, i64p]
+    L.rvm_debug_tap.restype = ci
+    L.rvm_launch_count.argtypes = [vp]
+    L.rvm_launch_count.restype = ci
+    L.rvm_set_graph_mode.argtypes = [vp, ci]
+    L.rvm_set_graph_mode.restype = ci
+    L.rvm_last_error.argtypes = []
+    L.rvm_last_error.restype = ctypes.c_char_p
+    L.rvm_version.argtypes = []
+    L.rvm_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rvm_last_error()
+        raise NativeError("%s failed: %s" % (what or "native call", msg.decode() if msg else "?"))
+
+
+class Context:
+    """Thin RAII wrapper over rvm_ctx*."""
+
+    def __init__(self, variant, refiner, dtype_code, device_index):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        check(L.rvm_create(VARIANTS[variant], REFINERS[refiner], dtype_code, device_index,
+                           ctypes.byref(self._h)), "rvm_create")
+        self.plan_key = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().rvm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def param_specs(self):
+        L = lib()
+        out = []
+        shape = (ctypes.c_int64 * 4)()
+        for i in range(L.rvm_param_count(self._h)):
+            nd = L.rvm_param_shape(self._h, i, shape)
+            out.append((L.rvm_param_name(self._h, i).decode(), tuple(shape[k] for k in range(nd))))
+        return out
+
+    def set_param(self, name, host_f32):
+        """host_f32: contiguous fp32 CPU torch tensor."""
+        check(lib().rvm_set_param(self._h, name.encode(), ctypes.c_void_p(host_f32.data_ptr()),
+                                  host_f32.numel()), "rvm_set_param(%s)" % name)
+
+    def finalize(self):
+        check(lib().rvm_finalize(self._h), "rvm_finalize")
+        self.plan_key = None
+
+    def plan(self, B, H, W, ds):
+        key = (B, H, W, float(ds))
+        if key != self.plan_key:
+            check(lib().rvm_plan(self._h, B, H, W, float(ds)), "rvm_plan")
+            self.plan_key = key
+
+    def state_shape(self, level):
+        shape = (ctypes.c_int64 * 4)()
+        check(lib().rvm_state_shape(self._h, level, shape), "rvm_state_shape")
+        return tuple(shape[k] for k in range(4))
+
+    def forward(self, src_ptr, r_in_ptrs, fgr_ptr, pha_ptr, r_out_ptrs, seg, stream):
+        rin = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) if p else None for p in r_in_ptrs])
+        rout = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) for p in r_out_ptrs])
+        check(lib().rvm_forward(self._h, ctypes.c_void_p(src_ptr), rin,
+                                ctypes.c_void_p(fgr_ptr) if fgr_ptr else None, ctypes.c_void_p(pha_ptr),
+                                rout, 1 if seg else 0, ctypes.c_void_p(stream)), "rvm_forward")
+
+    def launch_count(self):
+        return lib().rvm_launch_count(self._h)
+
+    def set_graph_mode(self, on):
+        check(lib().rvm_set_graph_mode(self._h, 1 if on else 0), "rvm_set_graph_mode")
+
+    def debug_tap(self, name):
+        import torch
+        shape = (ctypes.c_int64 * 4)()
+        check(lib().rvm_debug_tap(self._h, name.encode(), None, 0, shape), "rvm_debug_tap")
+        out = torch.empty(tuple(shape[k] for k in range(4)), dtype=torch.float32)
+        check(lib().rvm_debug_tap(self._h, name.encode(), ctypes.c_void_p(out.data_ptr()), out.numel(), shape),
+              "rvm_debug_tap")
+        return out
