@@ -65,6 +65,12 @@ int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capac
 /* Number of kernel launches one rvm_forward enqueues for the current plan. */
 int rvm_launch_count(const rvm_ctx* ctx);
 
+/* Per-launch metadata (name, algorithmic FLOPs and bytes as defined in DESIGN.md) and a profiled
+ * eager run that times every launch with hipEvents on `hip_stream` (synchronises). */
+int rvm_launch_info(const rvm_ctx* ctx, int index, char* name, int name_cap, double* flops, double* bytes);
+int rvm_profile_frame(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* fgr, void* pha,
+                      void* const r_out[4], void* hip_stream, float* ms_out, int ms_capacity);
+
 /* HIP-graph replay of the fixed per-frame schedule (pointers must stay the same between calls
  * for a replay to be valid; the graph is re-captured when they change). 0 = eager (default). */
 int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);

@@ -154,7 +154,7 @@ std::vector<ParamSpec> param_specs(int variant, int refiner) {
 struct PwLayer { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, KS = 0, NT = 0, act = 0; };
 struct DwLayer { size_t w = 0, bias = 0; int C = 0, K = 3, stride = 1, dil = 1, pad = 1, act = 0; };
 struct SeLayer { size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };
-struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0; };
+struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0, Cin = 0; };
 struct GruLayer { Conv3Layer ih, hh; int C = 0; };
 struct MbBlock { bool has_expand = false, has_se = false, res = false; PwLayer expand, project; DwLayer dw; SeLayer se; MbRow row; };
 
@@ -193,7 +193,11 @@ struct rvm_ctx {
     int lh[5], lw[5];
     char* arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
-    std::vector<std::function<void(hipStream_t, const FrameIO&)>> launches;
+    struct Launch {
+        std::string name; double flops, bytes;     // algorithmic work of the launch
+        std::function<void(hipStream_t, const FrameIO&)> fn;
+    };
+    std::vector<Launch> launches;
     std::map<std::string, Tap> taps;
 
     // graph mode
@@ -320,7 +324,7 @@ bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout
         for (int k = 0; k < srcOrig[s]; ++k) in_map[pc + k] = oc + k;
         pc += srcC[s]; oc += srcOrig[s];
     }
-    L.Cpad = (int)in_map.size(); L.Cout = Cout;
+    L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin;
     pack_frags(c, *W, cin, 9, out_map, in_map, af, L.w, L.bias, L.KS, L.NT);
     return true;
 }
@@ -491,7 +495,9 @@ int build_plan(rvm_ctx* c) {
     const int* lh = c->lh; const int* lw = c->lw;
     auto abuf = [&](size_t elems) { return (T*)c->arena_alloc(elems * es); };
     auto fbuf = [&](size_t elems) { return (float*)c->arena_alloc(elems * 4); };
-    auto add = [&](std::function<void(hipStream_t, const FrameIO&)> f) { c->launches.push_back(std::move(f)); };
+    auto add = [&](const std::string& name, double flops, double bytes, std::function<void(hipStream_t, const FrameIO&)> f) {
+        c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f)});
+    };
 
     // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
     T* s[4];
@@ -499,22 +505,28 @@ int build_plan(rvm_ctx* c) {
     {
         DownArgs a; a.s0 = s[0]; a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w;
         a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
-        add([=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, st); });
+        // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0 write
+        const double taps = (c->ds == 1.0) ? 1.0 : 4.0;
+        add("downsample", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps + 4) * es,
+            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, st); });
         for (int l = 1; l < 4; ++l) {
             PoolArgs p; p.x = s[l - 1]; p.y = s[l]; p.Hi = lh[l - 1]; p.Wi = lw[l - 1]; p.Ho = lh[l]; p.Wo = lw[l];
-            add([=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
+            add("avgpool_s" + std::to_string(l), 4.0 * B * p.Ho * p.Wo * 4, (double)B * (p.Hi * p.Wi + p.Ho * p.Wo) * 4 * es,
+                [=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
         }
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
-    auto pw = [&](const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
+    auto pw = [&](const std::string& name, const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
                   const float* out_scale, float* pool) {
         PwArgs a; memset(&a, 0, sizeof a);
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
         const int cfg = pick_pw_cfg(a.MT, a.NT, B);
-        add([=](hipStream_t st, const FrameIO&) { launch_pw<T>(a, B, cfg, st); });
+        add(name, 2.0 * B * HW * L.Cin * L.Cout,
+            ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
+            [=](hipStream_t st, const FrameIO&) { launch_pw<T>(a, B, cfg, st); });
     };
 
     // ---- encoder (mobilenetv3.py:36-60)
@@ -525,7 +537,8 @@ int build_plan(rvm_ctx* c) {
         a.Hi = lh[0]; a.Wi = lw[0]; a.Ho = lh[1]; a.Wo = lw[1];
         const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
         for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
-        add([=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
+        add("stem_conv3x3s2", 2.0 * B * a.Ho * a.Wo * 27 * 16, (double)B * (a.Hi * a.Wi * 4 + a.Ho * a.Wo * 16) * es,
+            [=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
     }
     T* f[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 15; ++i) {
@@ -537,7 +550,7 @@ int build_plan(rvm_ctx* c) {
         const T* ex = cur;
         if (b.has_expand) {
             T* e = abuf((size_t)B * Hi * Wi * exp);
-            pw(b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
+            pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
             ex = e;
         }
         T* dwo = abuf((size_t)B * Ho * Wo * exp);
@@ -553,7 +566,9 @@ int build_plan(rvm_ctx* c) {
             a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
             a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
             const int K = b.dw.K;
-            add([=](hipStream_t st, const FrameIO&) { launch_dw<T>(a, B, K, st); });
+            add("mb" + std::to_string(i + 1) + ".dw" + std::to_string(K) + "x" + std::to_string(K),
+                2.0 * B * npix * exp * K * K, (double)B * (Hi * Wi + npix) * exp * es,
+                [=](hipStream_t st, const FrameIO&) { launch_dw<T>(a, B, K, st); });
         }
         const T* scale = nullptr;
         if (b.has_se) {
@@ -567,12 +582,13 @@ int build_plan(rvm_ctx* c) {
             g2.xin = hidden; g2.nparts = 1; g2.part_stride = b.se.S; g2.xscale = 1.f;
             g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
             g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
-            add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
-            add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
+            const std::string sn = "mb" + std::to_string(i + 1) + ".se_fc";
+            add(sn + "1", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
+            add(sn + "2", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
             scale = sc;
         }
         T* out = abuf((size_t)B * npix * b.row.cout);
-        pw(b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+        pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
         cur = out; curC = b.row.cout; lvl = olvl;
         if (i == 0) f[0] = cur;
         if (i == 2) f[1] = cur;
@@ -582,7 +598,7 @@ int build_plan(rvm_ctx* c) {
     T* f4 = abuf((size_t)B * HW4 * c->enc_out);
     const int MT4 = cdiv(HW4, 16);
     float* f4pool = fbuf((size_t)B * MT4 * c->last.NT * 16);
-    pw(c->last, cur, curC, HW4, f4, c->enc_out, nullptr, nullptr, 0, nullptr, f4pool);
+    pw("features16_1x1", c->last, cur, curC, HW4, f4, c->enc_out, nullptr, nullptr, 0, nullptr, f4pool);
     c->taps["f1"] = Tap{f[0], B, lh[1], lw[1], c->feat[0], c->feat[0], false};
     c->taps["f2"] = Tap{f[1], B, lh[2], lw[2], c->feat[1], c->feat[1], false};
     c->taps["f3"] = Tap{f[2], B, lh[3], lw[3], c->feat[2], c->feat[2], false};
@@ -595,15 +611,15 @@ int build_plan(rvm_ctx* c) {
         g.xin = f4pool; g.nparts = MT4; g.part_stride = c->last.NT * 16; g.xscale = 1.f / (float)HW4;
         g.w = wb + c->aspp2_w; g.bias = nullptr; g.y = gate; g.y_is_T = 0; g.I = c->enc_out; g.O = c->aspp_c;
         g.act = ACT_SIGMOID; g.opw = 1;
-        add([=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g, B, st); });
+        add("aspp2_gate", 2.0 * B * g.I * g.O, (double)g.I * g.O * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g, B, st); });
     }
     const int AC = c->aspp_c;
     T* aspp = abuf((size_t)B * HW4 * AC);
-    pw(c->aspp1, f4, c->enc_out, HW4, aspp, AC, nullptr, nullptr, 0, gate, nullptr);
+    pw("aspp1_1x1", c->aspp1, f4, c->enc_out, HW4, aspp, AC, nullptr, nullptr, 0, gate, nullptr);
     c->taps["aspp"] = Tap{aspp, B, lh[4], lw[4], AC, AC, false};
 
     // ---- recurrent decoder (decoder.py:17-27)
-    auto conv3 = [&](const Conv3Layer& L, int Hh, int Ww, int epi, std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
+    auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Hh, int Ww, int epi, std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
         ConvArgs a; memset(&a, 0, sizeof a);
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
         a.H = Hh; a.W = Ww; a.tiles_x = cdiv(Ww, 16); a.epi = epi; a.Cout = L.Cout;
@@ -621,27 +637,29 @@ int build_plan(rvm_ctx* c) {
             if (blocks >= 256 || m == 1) { MW = m; break; }
         }
         if (conv3_lds_bytes<T>(MW, L.Cpad) > 160 * 1024) return fail("conv3x3: input patch does not fit LDS");
-        add([=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, st); });
+        add(name, 2.0 * B * Hh * Ww * 9 * L.Cin * L.Cout,
+            ((double)B * Hh * Ww * (L.Cin + L.Cout) + 9.0 * L.Cin * L.Cout) * es,
+            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, st); });
         return 0;
     };
     // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
-    auto gru = [&](const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
+    auto gru = [&](const std::string& name, const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
         const int C = G.C;
         T* rh = abuf((size_t)B * Hh * Ww * C);
         float* z = fbuf((size_t)B * Hh * Ww * C);
-        if (conv3(G.ih, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3(name + ".ih", G.ih, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
                 a.nsrc = 0;
                 a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0}; a.nsrc = 2;
                 a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z;
             })) return 1;
-        if (conv3(G.hh, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3(name + ".hh", G.hh, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0}; a.nsrc = 2;
                 a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx];
             })) return 1;
         return 0;
     };
         // decode4 (BottleneckBlock, decoder.py:63-67): a = aspp[:, :AC/2], b = aspp[:, AC/2:]
-    if (gru(c->gru[0], aspp + AC / 2, AC, lh[4], lw[4], 3)) return 1;
+    if (gru("decode4.gru", c->gru[0], aspp + AC / 2, AC, lh[4], lw[4], 3)) return 1;
     const T* xa = aspp; int xaC = AC / 2, xaS = AC;   // first half of the previous block output
     const T* skip[3] = {f[2], f[1], f[0]};
     const int skipC[3] = {c->feat[2], c->feat[1], c->feat[0]};
@@ -654,14 +672,14 @@ int build_plan(rvm_ctx* c) {
         const T* sl = s[l];
         const int Hs = lh[l + 1], Ws = lw[l + 1];
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
-        if (conv3(c->up[i], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
                 a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws};
                 a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0};
                 a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0};
                 a.nsrc = 4; a.y = X; a.ys = Cout;
             })) return 1;
-        if (gru(c->gru[i + 1], X + Cout / 2, Cout, lh[l], lw[l], hidx - 1)) return 1;
+        if (gru("decode" + std::to_string(l) + ".gru", c->gru[i + 1], X + Cout / 2, Cout, lh[l], lw[l], hidx - 1)) return 1;
         c->taps["x" + std::to_string(l)] = Tap{X, B, lh[l], lw[l], Cout, Cout, false};
         xa = X; xaC = Cout / 2; xaS = Cout;
     }
@@ -673,13 +691,13 @@ int build_plan(rvm_ctx* c) {
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
         const T* s0 = s[0];
         const int Hs = lh[1], Ws = lw[1];
-        if (conv3(c->out0, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3("decode0.conv0", c->out0, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
                 a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws};
                 a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
-        if (conv3(c->out1, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
+        if (conv3("decode0.conv1", c->out1, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
                 a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
             })) return 1;
     }
@@ -696,16 +714,27 @@ int build_plan(rvm_ctx* c) {
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
         ProjOutArgs po; po.hid = hid; po.wt = dw; po.H = c->h; po.W = c->w;
         const bool refine = c->ds != 1.0;
-        add([=](hipStream_t st, const FrameIO& io) {
-            if (io.seg || !refine) {
-                ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = io.seg;
-                launch_proj_out<T>(q, B, st);
-            } else {
-                launch_dgf_low<T>(lo, B, st);
-                DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
-                launch_dgf_apply<T>(q, B, st);
-            }
-        });
+        const double lowpx = (double)B * c->h * c->w, fullpx = (double)B * c->H * c->W;
+        if (refine) {
+            add("dgf_lowres", lowpx * 2.0 * (64 + 4 * 9 * 4 + 24 * 16 + 16 * 16 + 16 * 4), lowpx * (20 * es + 32),
+                [=](hipStream_t st, const FrameIO& io) { if (!io.seg) launch_dgf_low<T>(lo, B, st); });
+            add("dgf_apply_fullres", fullpx * 80.0, fullpx * 7 * es + lowpx * 32,
+                [=](hipStream_t st, const FrameIO& io) {
+                    if (io.seg) {
+                        ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = 1;
+                        launch_proj_out<T>(q, B, st);
+                    } else {
+                        DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
+                        launch_dgf_apply<T>(q, B, st);
+                    }
+                });
+        } else {
+            add("project_out", lowpx * 2.0 * 64, lowpx * (16 + 7) * es,
+                [=](hipStream_t st, const FrameIO& io) {
+                    ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = (int)io.seg;
+                    launch_proj_out<T>(q, B, st);
+                });
+        }
     }
     return 0;
 }
@@ -842,7 +871,7 @@ int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fg
     }
     hipStream_t st = (hipStream_t)hip_stream;
     if (!c->graph_mode) {
-        for (auto& f : c->launches) f(st, io);
+        for (auto& f : c->launches) f.fn(st, io);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -851,7 +880,7 @@ int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fg
     if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-    for (auto& f : c->launches) f(c->cap_stream, io);
+    for (auto& f : c->launches) f.fn(c->cap_stream, io);
     HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -859,6 +888,36 @@ int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fg
     if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back({io, exec});
     HIPCHK(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+int rvm_launch_info(const rvm_ctx* c, int i, char* name, int name_cap, double* flops, double* bytes) {
+    if (!c || i < 0 || i >= (int)c->launches.size()) return fail("rvm_launch_info: bad index");
+    const auto& L = c->launches[i];
+    if (name && name_cap > 0) { strncpy(name, L.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (flops) *flops = L.flops;
+    if (bytes) *bytes = L.bytes;
+    return 0;
+}
+
+// Eager run of one frame with a hipEvent pair around every launch on `hip_stream`; ms_out[i] is
+// the device time of launch i.  Synchronises.  Used by bench.py for the live roofline figure.
+int rvm_profile_frame(rvm_ctx* c, const void* src, const void* const r_in[4], void* fgr, void* pha,
+                      void* const r_out[4], void* hip_stream, float* ms_out, int cap) {
+    if (!c || !c->planned) return fail("rvm_profile_frame: no plan");
+    const int n = (int)c->launches.size();
+    if (!ms_out || cap < n) return fail("rvm_profile_frame: ms_out too small");
+    FrameIO io; memset(&io, 0, sizeof io);
+    io.src = src; io.fgr = fgr; io.pha = pha; io.seg = 0;
+    for (int i = 0; i < 4; ++i) { io.r_in[i] = r_in ? r_in[i] : nullptr; io.r_out[i] = r_out[i]; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(ev[0], st));
+    for (int i = 0; i < n; ++i) { c->launches[i].fn(st, io); HIPCHK(hipEventRecord(ev[i + 1], st)); }
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return 0;
 }
 

@@ -17,7 +17,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_state_shape", "rvm_forward",
-    "rvm_debug_tap", "rvm_launch_count", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -64,6 +64,11 @@ def lib():
     L.rvm_debug_tap.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
+    L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_double)]
+    L.rvm_launch_info.restype = ci
+    L.rvm_profile_frame.argtypes = [vp, vp, cpp, vp, vp, cpp, vp, ctypes.POINTER(ctypes.c_float), ci]
+    L.rvm_profile_frame.restype = ci
     L.rvm_set_graph_mode.argtypes = [vp, ci]
     L.rvm_set_graph_mode.restype = ci
     L.rvm_last_error.argtypes = []
@@ -139,6 +144,26 @@ class Context:
 
     def launch_count(self):
         return lib().rvm_launch_count(self._h)
+
+    def launch_info(self):
+        """[(name, algorithmic_flops, algorithmic_bytes)] for the current plan."""
+        out = []
+        buf = ctypes.create_string_buffer(128)
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        for i in range(self.launch_count()):
+            check(lib().rvm_launch_info(self._h, i, buf, 128, ctypes.byref(fl), ctypes.byref(by)), "rvm_launch_info")
+            out.append((buf.value.decode(), fl.value, by.value))
+        return out
+
+    def profile_frame(self, src_ptr, r_in_ptrs, fgr_ptr, pha_ptr, r_out_ptrs, stream):
+        n = self.launch_count()
+        ms = (ctypes.c_float * n)()
+        rin = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) if p else None for p in r_in_ptrs])
+        rout = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) for p in r_out_ptrs])
+        check(lib().rvm_profile_frame(self._h, ctypes.c_void_p(src_ptr), rin, ctypes.c_void_p(fgr_ptr),
+                                      ctypes.c_void_p(pha_ptr), rout, ctypes.c_void_p(stream), ms, n),
+              "rvm_profile_frame")
+        return list(ms)
 
     def set_graph_mode(self, on):
         check(lib().rvm_set_graph_mode(self._h, 1 if on else 0), "rvm_set_graph_mode")
