@@ -22,7 +22,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from robustvideomatting_amd import MattingNetwork, synthetic   # noqa: E402
+from robustvideomatting_amd import MattingNetwork, streams, synthetic   # noqa: E402
 
 WORKLOADS = {
     "hd": dict(H=1080, W=1920, ds=0.25, name="rvm_mobilenetv3 fp16 1x1920x1080 ds=0.25 (BASELINE configs[1])"),
@@ -30,7 +30,7 @@ WORKLOADS = {
     "small": dict(H=288, W=512, ds=1.0, name="rvm_mobilenetv3 512x288 ds=1 (BASELINE configs[0] shape)"),
 }
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
-MFMA_PEAK = {"fp16": 2.5e15, "fp32": 157.3e12}
+MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 157.3e12, "fp32": 157.3e12}   # by arithmetic type of the mode
 
 
 def frame_algorithmic_bytes(H, W, h, w, es):
@@ -70,7 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="hd", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16fast", "fp32"],
+                    help="fp16: fp16 tensors + fp32 arithmetic inside (parity-gated mode); fp16fast: fp16 storage + fp16 MFMA")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,12 +92,13 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     wl = WORKLOADS[a.workload]
-    tdt = torch.float16 if a.dtype == "fp16" else torch.float32
-    es = 2 if a.dtype == "fp16" else 4
+    tdt = torch.float32 if a.dtype == "fp32" else torch.float16
+    es = 4 if a.dtype == "fp32" else 2
 
     model = MattingNetwork("mobilenetv3", "deep_guided_filter").eval()
     model.load_state_dict(synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=0))
     model = model.to(dev, tdt)
+    model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")
     src = synthetic.make_clip(1, wl["H"], wl["W"], seed=rank, B=a.batch)[:, 0].to(dev, tdt).contiguous()
     ds = wl["ds"]
@@ -107,24 +109,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    rec = [None] * 4
+    # rank r owns streams {r, r+world, ...} of the world*batch streams; they advance together as one batch
+    ids = streams.shard_streams(world * a.batch, world, rank)
+    runner = streams.StreamRunner(model, ids, ds)
     with torch.no_grad():
         for _ in range(a.warmup):
-            out = model(src, None, *rec, ds)
-            rec = out[2:]
+            out = runner.step(src)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            out = model(src, None, *rec, ds)
-            rec = out[2:]
+            out = runner.step(src)
         sync_all()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    frames = a.steps * a.batch * world
-    fps = frames / dt
+        dt_local = time.perf_counter() - t0
+    fps, frames, dt = streams.aggregate_throughput(a.steps * a.batch, dt_local, dist, dev)
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
 
     roof = None
@@ -176,7 +173,7 @@ def main():
             "metric": "frames/sec, rvm_mobilenetv3 at HD ds=0.25 and 4K ds=0.125, 1->8 GPUs",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp16": "f32 arithmetic, f16 tensors", "fp16fast": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "mode": a.mode,
                        "parallelism": "stream-sharded, %d independent stream(s), no collective" % (world * a.batch)},
             "roofline": roof, "cpu_baseline": cpu,

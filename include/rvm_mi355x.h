@@ -23,7 +23,11 @@ extern "C" {
 
 typedef struct rvm_ctx rvm_ctx;
 
-enum { RVM_DTYPE_F32 = 0, RVM_DTYPE_F16 = 1 };
+/* RVM_DTYPE_F32   : fp32 tensors, fp32 arithmetic (v_mfma_f32_16x16x4_f32)
+ * RVM_DTYPE_F16   : fp16 tensors, fp16 storage and v_mfma_f32_16x16x32_f16 inside (fastest, fp16 accuracy)
+ * RVM_DTYPE_F16IO : fp16 tensors at the boundary (src, fgr, pha, r1..r4), fp32 storage and arithmetic
+ *                   inside - the mode that meets the 2e-3 fp16 parity bound on any weights */
+enum { RVM_DTYPE_F32 = 0, RVM_DTYPE_F16 = 1, RVM_DTYPE_F16IO = 2 };
 enum { RVM_VARIANT_MOBILENETV3 = 0, RVM_VARIANT_RESNET50 = 1 };
 enum { RVM_REFINER_DEEP_GUIDED_FILTER = 0, RVM_REFINER_FAST_GUIDED_FILTER = 1 };
 

@@ -55,7 +55,7 @@ struct GemvArgs {
 };
 
 // ---- 3x3 implicit-GEMM conv (decoder, ConvGRU) ----------------------------------------------
-struct ConvSrc { const void* p; int C; int Cs; int up; int Hs; int Ws; };
+struct ConvSrc { const void* p; int C; int Cs; int up; int Hs; int Ws; int f16; };   // f16: fp16 tensor feeding an fp32 kernel
 enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
 struct ConvArgs {
     ConvSrc src[4]; int nsrc; int Cpad; int ql_log2;
@@ -65,6 +65,7 @@ struct ConvArgs {
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
     void* hout;                             // GRU new state [N][H][W][hC]
+    int state16;                            // hprev / hout are fp16 although the kernel computes in fp32
 };
 
 // ---- stem ---------------------------------------------------------------------------------
@@ -99,10 +100,10 @@ template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t 
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, hipStream_t s);
 template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s);
-template <typename T> void launch_down(const DownArgs& a, int N, hipStream_t s);
+template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
-template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, hipStream_t s);
-template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, hipStream_t s);
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> size_t conv3_lds_bytes(int MW, int Cpad);
 void kernels_init();   // one-time function attributes (dynamic LDS limits)

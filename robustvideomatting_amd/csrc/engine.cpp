@@ -206,7 +206,7 @@ struct rvm_ctx {
     struct GraphEntry { FrameIO key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
 
-    size_t esize() const { return dtype == RVM_DTYPE_F16 ? 2 : 4; }
+    size_t esize() const { return dtype == RVM_DTYPE_F16 ? 2 : 4; }          // internal element size
     const std::vector<float>* P(const std::string& n) const {
         auto it = params.find(n);
         return it == params.end() ? nullptr : &it->second;
@@ -491,6 +491,8 @@ int build_plan(rvm_ctx* c) {
     c->arena_used = 0;
     const int B = c->B;
     const size_t es = sizeof(T);
+    const int io16 = c->dtype == RVM_DTYPE_F16IO ? 1 : 0;   // fp16 tensors at the boundary, fp32 inside
+    const size_t ies = c->dtype == RVM_DTYPE_F32 ? 4 : 2;   // element size of src / fgr / pha
     char* wb = c->wdev;
     const int* lh = c->lh; const int* lw = c->lw;
     auto abuf = [&](size_t elems) { return (T*)c->arena_alloc(elems * es); };
@@ -507,8 +509,8 @@ int build_plan(rvm_ctx* c) {
         a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
         // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0 write
         const double taps = (c->ds == 1.0) ? 1.0 : 4.0;
-        add("downsample", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps + 4) * es,
-            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, st); });
+        add("downsample", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps * ies + 4 * es),
+            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); });
         for (int l = 1; l < 4; ++l) {
             PoolArgs p; p.x = s[l - 1]; p.y = s[l]; p.Hi = lh[l - 1]; p.Wi = lw[l - 1]; p.Ho = lh[l]; p.Wo = lw[l];
             add("avgpool_s" + std::to_string(l), 4.0 * B * p.Ho * p.Wo * 4, (double)B * (p.Hi * p.Wi + p.Ho * p.Wo) * 4 * es,
@@ -649,12 +651,12 @@ int build_plan(rvm_ctx* c) {
         float* z = fbuf((size_t)B * Hh * Ww * C);
         if (conv3(name + ".ih", G.ih, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
                 a.nsrc = 0;
-                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0}; a.nsrc = 2;
-                a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z;
+                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0, io16}; a.nsrc = 2;
+                a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z; a.state16 = io16;
             })) return 1;
         if (conv3(name + ".hh", G.hh, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
-                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0}; a.nsrc = 2;
-                a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx];
+                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0, 0}; a.nsrc = 2;
+                a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx]; a.state16 = io16;
             })) return 1;
         return 0;
     };
@@ -673,10 +675,10 @@ int build_plan(rvm_ctx* c) {
         const int Hs = lh[l + 1], Ws = lw[l + 1];
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
         if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
-                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
-                a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws};
-                a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0};
-                a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0};
+                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
+                a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0, 0};
+                a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 4; a.y = X; a.ys = Cout;
             })) return 1;
         if (gru("decode" + std::to_string(l) + ".gru", c->gru[i + 1], X + Cout / 2, Cout, lh[l], lw[l], hidx - 1)) return 1;
@@ -692,13 +694,13 @@ int build_plan(rvm_ctx* c) {
         const T* s0 = s[0];
         const int Hs = lh[1], Ws = lw[1];
         if (conv3("decode0.conv0", c->out0, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
-                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws};
-                a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws};
-                a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0};
+                a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
+                a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
         if (conv3("decode0.conv1", c->out1, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
-                a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
+                a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
             })) return 1;
     }
     c->taps["hid"] = Tap{hid, B, c->h, c->w, HC, HC, false};
@@ -718,21 +720,21 @@ int build_plan(rvm_ctx* c) {
         if (refine) {
             add("dgf_lowres", lowpx * 2.0 * (64 + 4 * 9 * 4 + 24 * 16 + 16 * 16 + 16 * 4), lowpx * (20 * es + 32),
                 [=](hipStream_t st, const FrameIO& io) { if (!io.seg) launch_dgf_low<T>(lo, B, st); });
-            add("dgf_apply_fullres", fullpx * 80.0, fullpx * 7 * es + lowpx * 32,
+            add("dgf_apply_fullres", fullpx * 80.0, fullpx * 7 * ies + lowpx * 32,
                 [=](hipStream_t st, const FrameIO& io) {
                     if (io.seg) {
                         ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = 1;
-                        launch_proj_out<T>(q, B, st);
+                        launch_proj_out<T>(q, B, io16, st);
                     } else {
                         DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
-                        launch_dgf_apply<T>(q, B, st);
+                        launch_dgf_apply<T>(q, B, io16, st);
                     }
                 });
         } else {
-            add("project_out", lowpx * 2.0 * 64, lowpx * (16 + 7) * es,
+            add("project_out", lowpx * 2.0 * 64, lowpx * (16 * es + 7 * ies),
                 [=](hipStream_t st, const FrameIO& io) {
                     ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = (int)io.seg;
-                    launch_proj_out<T>(q, B, st);
+                    launch_proj_out<T>(q, B, io16, st);
                 });
         }
     }
@@ -780,7 +782,7 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     *out = nullptr;
     if (variant != RVM_VARIANT_MOBILENETV3 && variant != RVM_VARIANT_RESNET50) return fail("rvm_create: bad variant");
     if (refiner != RVM_REFINER_DEEP_GUIDED_FILTER && refiner != RVM_REFINER_FAST_GUIDED_FILTER) return fail("rvm_create: bad refiner");
-    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16) return fail("rvm_create: bad dtype");
+    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO) return fail("rvm_create: bad dtype");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("rvm_create: no such HIP device");

@@ -35,6 +35,14 @@ __device__ __forceinline__ void st8f(f16* p, F8 v) {
 }
 __device__ __forceinline__ void st8f(float* p, F8 v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
 
+// element-typed access through a runtime flag (fp16 tensors at the API boundary of the mixed mode)
+__device__ __forceinline__ f32x4 ld4x(const void* p, size_t i, bool half) {
+    return half ? ld4f((const f16*)p + i) : ld4f((const float*)p + i);
+}
+__device__ __forceinline__ void st4x(void* p, size_t i, bool half, f32x4 v) {
+    if (half) st4f((f16*)p + i, v); else st4f((float*)p + i, v);
+}
+
 // MFMA operand fragments: 8 K-elements per lane.
 template <typename T> struct Frag;
 template <> struct Frag<f16> {
@@ -343,16 +351,16 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
                 f32x4 v = f32x4{0, 0, 0, 0};
                 if (inb && s < a.nsrc && a.src[s].p) {
                     const ConvSrc& S = a.src[s];
-                    const T* p = (const T*)S.p;
+                    const bool hf = sizeof(T) == 2 || S.f16;
                     if (!S.up) {
-                        v = ld4f(p + (((size_t)n * H + gy) * W + gx) * S.Cs + cc);
+                        v = ld4x(S.p, (((size_t)n * H + gy) * W + gx) * S.Cs + cc, hf);
                     } else {
                         const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
-                        const T* b = p + (size_t)n * S.Hs * S.Ws * S.Cs + cc;
-                        f32x4 v00 = ld4f(b + ((size_t)iy0 * S.Ws + ix0) * S.Cs);
-                        f32x4 v01 = ld4f(b + ((size_t)iy0 * S.Ws + ix1) * S.Cs);
-                        f32x4 v10 = ld4f(b + ((size_t)iy1 * S.Ws + ix0) * S.Cs);
-                        f32x4 v11 = ld4f(b + ((size_t)iy1 * S.Ws + ix1) * S.Cs);
+                        const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + cc;
+                        f32x4 v00 = ld4x(S.p, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
+                        f32x4 v01 = ld4x(S.p, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
+                        f32x4 v10 = ld4x(S.p, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
+                        f32x4 v11 = ld4x(S.p, b + ((size_t)iy1 * S.Ws + ix1) * S.Cs, hf);
                         v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
                     }
                 }
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
                     f32x4 rv = acc[mi][ni] + *(const f32x4*)(a.bias + t * 16 + g * 4);
                     f32x4 zv = acc[mi][ni + 1] + *(const f32x4*)(a.bias + (t + 1) * 16 + g * 4);
                     f32x4 h = f32x4{0, 0, 0, 0};
-                    if (a.hprev) h = ld4f((const T*)a.hprev + pix * a.hC + c);
+                    if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, sizeof(T) == 2 || a.state16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { rv[r] = sigmoid_f(rv[r]) * h[r]; zv[r] = sigmoid_f(zv[r]); }
                     st4f((T*)a.rh + pix * a.hC + c, rv);
@@ -448,11 +456,11 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
                 if (!nv[ni] || c >= a.hC) continue;
                 f32x4 cv = acc[mi][ni] + *(const f32x4*)(a.bias + c);
                 f32x4 h = f32x4{0, 0, 0, 0};
-                if (a.hprev) h = ld4f((const T*)a.hprev + pix * a.hC + c);
+                if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, sizeof(T) == 2 || a.state16);
                 const f32x4 z = *(const f32x4*)(a.z + pix * a.hC + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
-                st4f((T*)a.hout + pix * a.hC + c, cv);
+                st4x(a.hout, pix * a.hC + c, sizeof(T) == 2 || a.state16, cv);
             }
         }
     }
@@ -527,7 +535,7 @@ template void launch_stem<float>(const StemArgs&, int, hipStream_t);
 // bilinear coordinates (model/model.py:80-81: align_corners=False,
 // recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (p >= a.h * a.w) return;
@@ -539,11 +547,11 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     if (x0 > a.W - 1) x0 = a.W - 1;
     const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
     const float ly = sy - y0, lx = sx - x0;
-    const T* sp = (const T*)a.src + (size_t)n * 3 * a.H * a.W;
+    const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * a.H * a.W;
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const T* pl = sp + (size_t)c * a.H * a.W;
+        const TIO* pl = sp + (size_t)c * a.H * a.W;
         const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
         const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
         o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
@@ -552,11 +560,12 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     o[3] = (o[0] + o[1] + o[2]) / 3.f;
     st4f((T*)a.s0 + ((size_t)n * a.h * a.w + p) * 4, o);
 }
-template <typename T> void launch_down(const DownArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((downsample<T>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
+template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
+    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((downsample<T, T>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
 }
-template void launch_down<f16>(const DownArgs&, int, hipStream_t);
-template void launch_down<float>(const DownArgs&, int, hipStream_t);
+template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
+template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
 
 // 2x2 stride-2 average pool, ceil_mode, count_include_pad=False (decoder.py:33) on NHWC4.
 template <typename T>
@@ -623,16 +632,38 @@ __global__ __launch_bounds__(256) void dgf_lowres(DgfLowArgs a) {
     const int gy = y0 + ly, gx = x0 + lx;
     if (gy >= a.h || gx >= a.w) return;
     f32x4 mx = f32x4{0, 0, 0, 0}, my = mx, exy = mx, exx = mx;
+    if (a.fast) {
+        // separable 1/3 box, horizontal then vertical, like fast_guided_filter.py:71-76
+        const float t3 = 1.0f / 3.0f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int pp = (ly + t / 3) * 18 + lx + t % 3;
-        const f32x4 xv = sx[pp], yv = sy[pp];
-        f32x4 bw;
+        for (int dy = 0; dy < 3; ++dy) {
+            f32x4 rx = mx * 0.f, ry = rx, rxy = rx, rxx = rx;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bw[c] = wt.box[c][t];
-        mx += bw * xv; my += bw * yv; exy += bw * (xv * yv); exx += bw * (xv * xv);
+            for (int dx = 0; dx < 3; ++dx) {
+                const int pp = (ly + dy) * 18 + lx + dx;
+                const f32x4 xv = sx[pp], yv = sy[pp];
+                rx += xv * t3; ry += yv * t3; rxy += (xv * yv) * t3; rxx += (xv * xv) * t3;
+            }
+            mx += rx * t3; my += ry * t3; exy += rxy * t3; exx += rxx * t3;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pp = (ly + t / 3) * 18 + lx + t % 3;
+            const f32x4 xv = sx[pp], yv = sy[pp];
+            f32x4 bw;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bw[c] = wt.box[c][t];
+            mx += bw * xv; my += bw * yv; exy += bw * (xv * yv); exx += bw * (xv * xv);
+        }
     }
-    const f32x4 cov = exy - mx * my, var = exx - mx * mx;
+    // no fma contraction here: E[xy]-E[x]E[y] cancels, keep the reference's rounding sequence
+    f32x4 cov, var;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cov[c] = __fsub_rn(exy[c], __fmul_rn(mx[c], my[c]));
+        var[c] = __fsub_rn(exx[c], __fmul_rn(mx[c], mx[c]));
+    }
     f32x4 A;
     if (a.fast) {
         A = cov / (var + 1e-5f);
@@ -684,7 +715,7 @@ template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
 // 37-39), out = A*[src,gray]+b (:41), fgr = clamp(out+src), pha = clamp(out) (model.py:65-67).
 // One pass: src read once, fgr/pha written once; a thread owns 8 consecutive x.
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename TIO>
 __global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
     const int y = blockIdx.y, n = blockIdx.z;
@@ -696,9 +727,9 @@ __global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
     const float* r0 = a.ab + ((size_t)n * a.h + iy0) * a.w * 8;
     const float* r1 = a.ab + ((size_t)n * a.h + iy1) * a.w * 8;
     const size_t plane = (size_t)a.H * a.W;
-    const T* sp = (const T*)a.src + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    T* fp = (T*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    T* pp = (T*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
+    const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
+    TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
+    TIO* pp = (TIO*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
     const bool full = (x0 + 8 <= a.W) && ((a.W & 7) == 0);
     float s[3][8];
     if (full) {
@@ -761,24 +792,25 @@ __global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
         for (int j = 0; j < 8; ++j) {
             if (x0 + j < a.W) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) fp[c * plane + j] = (T)of[c][j];
-                pp[j] = (T)op[j];
+                for (int c = 0; c < 3; ++c) fp[c * plane + j] = (TIO)of[c][j];
+                pp[j] = (TIO)op[j];
             }
         }
     }
 }
-template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, hipStream_t s) {
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s) {
     const int groups = (a.W + 7) / 8;
-    hipLaunchKernelGGL((dgf_apply<T>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
+    if (sizeof(T) == 2 || io16) hipLaunchKernelGGL((dgf_apply<f16>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dgf_apply<float>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
 }
-template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, hipStream_t);
-template void launch_dgf_apply<float>(const DgfApplyArgs&, int, hipStream_t);
+template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, bool, hipStream_t);
+template void launch_dgf_apply<float>(const DgfApplyArgs&, int, bool, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // downsample_ratio == 1 tail (no refiner): project_mat + residual + clamp (model.py:62,65-67)
 // or project_seg (model.py:70) when seg != 0 (written to `pha`, no clamp).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     const int HW = a.H * a.W;
@@ -793,7 +825,7 @@ __global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
         float s = wt.seg_b;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += wt.seg_w[k] * hv[k];
-        ((T*)a.pha)[(size_t)n * HW + p] = (T)s;
+        ((TIO*)a.pha)[(size_t)n * HW + p] = (TIO)s;
         return;
     }
     float y[4];
@@ -804,17 +836,18 @@ __global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
         for (int k = 0; k < 16; ++k) s += wt.proj_w[o][k] * hv[k];
         y[o] = s;
     }
-    const T* sp = (const T*)a.src + (size_t)n * 3 * HW + p;
-    T* fp = (T*)a.fgr + (size_t)n * 3 * HW + p;
+    const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * HW + p;
+    TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * HW + p;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) fp[(size_t)c * HW] = (T)fminf(fmaxf(y[c] + (float)sp[(size_t)c * HW], 0.f), 1.f);
-    ((T*)a.pha)[(size_t)n * HW + p] = (T)fminf(fmaxf(y[3], 0.f), 1.f);
+    for (int c = 0; c < 3; ++c) fp[(size_t)c * HW] = (TIO)fminf(fmaxf(y[c] + (float)sp[(size_t)c * HW], 0.f), 1.f);
+    ((TIO*)a.pha)[(size_t)n * HW + p] = (TIO)fminf(fmaxf(y[3], 0.f), 1.f);
 }
-template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((proj_out<T>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s) {
+    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((proj_out<T, f16>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((proj_out<T, T>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
 }
-template void launch_proj_out<f16>(const ProjOutArgs&, int, hipStream_t);
-template void launch_proj_out<float>(const ProjOutArgs&, int, hipStream_t);
+template void launch_proj_out<f16>(const ProjOutArgs&, int, bool, hipStream_t);
+template void launch_proj_out<float>(const ProjOutArgs&, int, bool, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 template <typename T, int MW, int NW> static void conv3_attr() {

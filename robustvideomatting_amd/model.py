@@ -85,24 +85,42 @@ class MattingNetwork(nn.Module):
                 node.register_buffer(parts[-1], value)
             else:
                 node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+        self._master = None         # fp32 master copies (see _snapshot_masters)
         self._ctx = None            # native.Context
         self._ctx_key = None        # (device index, dtype)
         self._dirty = True          # parameters changed since the last upload
         self._graph = False
+        self.fp16_arithmetic = "fp32"   # half() module: "fp32" = fp16 tensors, fp32 math inside (meets 2e-3);
+        #                                 "fp16" = fp16 storage + fp16 MFMA inside (fastest, fp16 accuracy)
         self._ring = {}             # plan key -> ring of static output/state buffers (graph mode)
         self._ring_pos = 0
 
-    # ---- bookkeeping: any .to()/.half()/.cuda()/load_state_dict invalidates the packed weights
+    # ---- bookkeeping: any .to()/.half()/.cuda()/load_state_dict invalidates the packed weights.
+    # fp32 MASTER copies of the parameters are kept across .half(): the native packer folds
+    # BatchNorm and rounds ONCE from them, instead of inheriting the rounding `.half()` applied to
+    # every raw tensor (which alone moves pha by >2e-3 on the synthetic stress weights).
+    def _snapshot_masters(self):
+        w = self.project_mat.conv.weight
+        if w.dtype == torch.float32:
+            self._master = {k: v.detach().to("cpu", torch.float32).clone()
+                            for k, v in self.state_dict().items() if v.is_floating_point()}
+
     def _apply(self, fn, *args, **kwargs):
-        self._dirty = True
+        if getattr(self, "_names", None) is not None:
+            self._snapshot_masters()
+            self._dirty = True
         return super()._apply(fn, *args, **kwargs)
 
-    def load_state_dict(self, *args, **kwargs):
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        res = super().load_state_dict(state_dict, *args, **kwargs)
+        self._master = {k: v.detach().to("cpu", torch.float32).clone()
+                        for k, v in state_dict.items() if torch.is_tensor(v) and v.is_floating_point()}
         self._dirty = True
-        return super().load_state_dict(*args, **kwargs)
+        return res
 
     def refresh(self):
-        """Call after modifying parameters in place."""
+        """Call after modifying parameters in place: drops the fp32 masters and re-uploads."""
+        self._master = None
         self._dirty = True
 
     def enable_graph(self, on: bool = True):
@@ -118,7 +136,9 @@ class MattingNetwork(nn.Module):
         if dtype == torch.float32:
             code = native.DTYPE_F32
         elif dtype == torch.float16:
-            code = native.DTYPE_F16
+            if self.fp16_arithmetic not in ("fp32", "fp16"):
+                raise RuntimeError("fp16_arithmetic must be 'fp32' or 'fp16'")
+            code = native.DTYPE_F16IO if self.fp16_arithmetic == "fp32" else native.DTYPE_F16
         else:
             raise RuntimeError("MattingNetwork (MI355X): unsupported dtype %s (float32 / float16)" % dtype)
         key = (device.index if device.index is not None else torch.cuda.current_device(), code)
@@ -135,7 +155,10 @@ class MattingNetwork(nn.Module):
             for name, shape in self._ctx.param_specs():
                 if len(shape) == 0:
                     continue
-                t = sd[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+                t = self._master.get(name) if self._master else None
+                if t is None or tuple(t.shape) != tuple(sd[name].shape):
+                    t = sd[name]
+                t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
                 if tuple(t.shape) != shape:
                     raise RuntimeError("parameter %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
                 self._ctx.set_param(name, t)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librvm_mi355x.so")
 
-DTYPE_F32, DTYPE_F16 = 0, 1
+DTYPE_F32, DTYPE_F16, DTYPE_F16IO = 0, 1, 2
 VARIANTS = {"mobilenetv3": 0, "resnet50": 1}
 REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 

@@ -80,10 +80,11 @@ def make_params(variant="mobilenetv3", refiner="deep_guided_filter", seed=0,
             out[name] = randn(shape, gain / math.sqrt(fan_in))
             if name == "project_mat.conv.weight":
                 out[name][:3] *= 0.3                     # keep fgr = src + residual mostly inside (0,1)
+                out[name][3] *= 0.5                      # keep pha inside (0,1): the clamp must not hide errors
     return out
 
 
-def make_clip(T, H, W, seed=0, B=1, dtype=torch.float32):
+def make_clip(T, H, W, seed=0, B=1, dtype=torch.float32, noise=0.04):
     """[B,T,3,H,W] clip in [0,1]: smooth static background + moving soft ellipse + noise."""
     g = torch.Generator().manual_seed(1000 + seed)
     clips = []
@@ -109,7 +110,7 @@ def make_clip(T, H, W, seed=0, B=1, dtype=torch.float32):
             d2 = ((xs - cx) / 0.18) ** 2 + ((ys - cy) / 0.30) ** 2
             m = torch.sigmoid((1.0 - d2) * 6.0)
             fr = bg * (1 - m) + col.view(3, 1, 1) * m
-            fr = fr + (torch.rand(3, H, W, generator=g) - 0.5) * 0.04
+            fr = fr + (torch.rand(3, H, W, generator=g) - 0.5) * noise
             frames.append(fr.clamp(0, 1))
         clips.append(torch.stack(frames))
     return torch.stack(clips).to(dtype)

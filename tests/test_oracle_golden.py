@@ -1,0 +1,101 @@
+"""CPU: the oracle against the golden vectors produced by the reference's own classes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rvm_oracle as O
+from robustvideomatting_amd import spec, synthetic
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("variant", ["mobilenetv3", "resnet50"])
+def test_oracle_matches_reference_blocks(variant):
+    """ref_blocks_*.npz hold outputs of reference model/{lraspp,decoder,deep_guided_filter,
+    fast_guided_filter}.py run in the build container (oracle/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "ref_blocks_%s.npz" % variant))
+    p = synthetic.make_params(variant, "deep_guided_filter", seed=3, perturb_box_filter=True)
+    # LR-ASPP
+    assert (O.lraspp(p, _t(g["aspp_in"])) - _t(g["aspp_out"])).abs().max() < 1e-5
+    # decoder, 3 frames with carried state (first frame from r=None)
+    s0, f1, f2, f3, f4 = (_t(g["dec_" + k]) for k in ("s0", "f1", "f2", "f3", "f4"))
+    rec = [None] * 4
+    hid0 = None
+    for t in range(s0.shape[1]):
+        out = O.decoder(p, s0[:, t], f1[:, t], f2[:, t], f3[:, t], f4[:, t], *rec)
+        rec = list(out[1:])
+        assert (out[0] - _t(g["dec_hid"])[:, t]).abs().max() < 1e-5
+        if t == 0:
+            hid0 = out[0]
+    for i in range(4):
+        assert (rec[i] - _t(g["dec_r%d" % (i + 1)])).abs().max() < 1e-5
+    # projection
+    y = torch.nn.functional.conv2d(hid0, p["project_mat.conv.weight"], p["project_mat.conv.bias"])
+    assert (y - _t(g["proj_out"])).abs().max() < 1e-5
+    # refiners
+    fine, base, fgr, pha = (_t(g["ref_" + k]) for k in ("fine", "base", "fgr", "pha"))
+    a = O.deep_guided_filter(p, fine, base, fgr, pha, hid0)
+    assert (a[0] - _t(g["dgf_fgr"])).abs().max() < 1e-5 and (a[1] - _t(g["dgf_pha"])).abs().max() < 1e-5
+    b = O.fast_guided_filter(fine, base, fgr, pha)
+    assert (b[0] - _t(g["fgf_fgr"])).abs().max() < 2e-5 and (b[1] - _t(g["fgf_pha"])).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast", "resnet50_ds025"])
+def test_e2e_fixture_frozen(name):
+    """End-to-end vectors: the oracle reproduces what was committed (guards accidental edits)."""
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % name))
+    H, W, T, seed = (int(x) for x in g["meta"])
+    ds, refiner = float(g["ds"]), str(g["refiner"])
+    variant = name.split("_")[0]
+    p = synthetic.make_params(variant, refiner, seed=seed)
+    clip = synthetic.make_clip(T, H, W, seed=seed)
+    out = O.forward(p, clip, downsample_ratio=ds, variant=variant, refiner=refiner)
+    assert (out[0] - _t(g["fgr"]).float()).abs().max() < 1e-3          # stored as fp16
+    assert (out[0][:, -1] - _t(g["fgr_last"])).abs().max() < 2e-5
+    assert (out[1] - _t(g["pha"])).abs().max() < 2e-5
+    for i in range(4):
+        assert (out[2 + i] - _t(g["r%d" % (i + 1)])).abs().max() < 2e-5
+
+
+def test_activation_ranges():
+    """Synthetic weights must keep every tap O(1) and the outputs un-saturated, otherwise
+    clamps / saturated gates would hide kernel errors."""
+    p = synthetic.make_params(seed=0)
+    clip = synthetic.make_clip(2, 144, 256, seed=0)
+    taps = []
+    out = O.forward(p, clip, downsample_ratio=0.5, taps=taps)
+    t = taps[-1]
+    for k in ("f1", "f2", "f3", "f4", "aspp", "x3", "x2", "x1", "hid"):
+        sd = t[k].std().item()
+        assert 0.05 < sd < 5.0, (k, sd)
+    inside = ((out[1] > 0) & (out[1] < 1)).float().mean().item()
+    assert inside > 0.8
+    for r in out[2:]:
+        assert 0.05 < r.std().item() and r.abs().max().item() <= 1.0
+
+
+def test_time_series_equals_framewise():
+    p = synthetic.make_params(seed=1)
+    clip = synthetic.make_clip(3, 40, 56, seed=1)
+    a = O.forward(p, clip, downsample_ratio=1.0)
+    rec = [None] * 4
+    for t in range(3):
+        o = O.forward(p, clip[:, t], *rec, downsample_ratio=1.0)
+        rec = o[2:]
+        assert torch.equal(o[1], a[1][:, t])
+    for x, y in zip(rec, a[2:]):
+        assert torch.equal(x, y)
+
+
+def test_spec_sizes():
+    assert spec.lowres_size(1080, 1920, 0.25) == (270, 480)
+    assert spec.lowres_size(2160, 3840, 0.125) == (270, 480)
+    assert spec.pyramid_sizes(270, 480) == [(135, 240), (68, 120), (34, 60), (17, 30)]
+    assert spec.state_channels("mobilenetv3") == [16, 20, 40, 64]
+    assert spec.state_channels("resnet50") == [16, 32, 64, 128]

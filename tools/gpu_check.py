@@ -17,15 +17,17 @@ TAPS = ["s0", "s1", "s2", "s3", "f1", "f2", "f3", "f4", "aspp", "x3", "x2", "x1"
 
 
 def run(dtype="fp32", H=122, W=218, ds=0.25, T=3, B=1, variant="mobilenetv3", refiner="deep_guided_filter",
-        seed=0, verbose=True, graph=False):
+        seed=0, verbose=True, graph=False, noise=0.04):
+    # dtype: fp32 | fp16 (fp16 tensors, fp32 arithmetic inside) | fp16fast (fp16 storage + fp16 MFMA)
     tdt = torch.float32 if dtype == "fp32" else torch.float16
     params = synthetic.make_params(variant, refiner, seed=seed, perturb_box_filter=True)
     model = MattingNetwork(variant, refiner).eval()
     model.load_state_dict(params)
     model = model.to("cuda", tdt)
+    model.fp16_arithmetic = "fp16" if dtype == "fp16fast" else "fp32"
     if graph:
         model.enable_graph(True)
-    clip = synthetic.make_clip(T, H, W, seed=seed, B=B)                 # [B,T,3,H,W] fp32
+    clip = synthetic.make_clip(T, H, W, seed=seed, B=B, noise=noise)    # [B,T,3,H,W] fp32
     clip_dev = clip.to("cuda", tdt)
     clip_ref = clip_dev.float().cpu()                                   # what the device actually sees
     rec_g, rec_o = [None] * 4, [None] * 4
