@@ -75,8 +75,8 @@ struct StemArgs {
 };
 
 // ---- resize / pyramid ----------------------------------------------------------------------
-struct DownArgs { const void* src; void* s0; int H, W, h, w; float scale_y, scale_x; };
-struct PoolArgs { const void* x; void* y; int Hi, Wi, Ho, Wo; };
+struct DownArgs { const void* src; void* s0; void* s1; int H, W, h, w, h1, w1; float scale_y, scale_x; };
+struct PoolArgs { const void* s1; void* s2; void* s3; int H1, W1, H2, W2, H3, W3; };
 
 // ---- refiner ------------------------------------------------------------------------------
 struct DgfWeights {                          // device blob layout (floats)
@@ -106,4 +106,7 @@ template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> size_t conv3_lds_bytes(int MW, int Cpad);
+void dw_block_shape(int C, int* cgb, int* pyb);
+size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
+template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);
 void kernels_init();   // one-time function attributes (dynamic LDS limits)

@@ -505,17 +505,16 @@ int build_plan(rvm_ctx* c) {
     T* s[4];
     for (int l = 0; l < 4; ++l) s[l] = abuf((size_t)B * lh[l] * lw[l] * 4);
     {
-        DownArgs a; a.s0 = s[0]; a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w;
+        DownArgs a; a.s0 = s[0]; a.s1 = s[1]; a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w; a.h1 = lh[1]; a.w1 = lw[1];
         a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
-        // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0 write
+        // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0, s1 writes
         const double taps = (c->ds == 1.0) ? 1.0 : 4.0;
-        add("downsample", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps * ies + 4 * es),
+        add("downsample_s0s1", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps * ies + 5 * es),
             [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); });
-        for (int l = 1; l < 4; ++l) {
-            PoolArgs p; p.x = s[l - 1]; p.y = s[l]; p.Hi = lh[l - 1]; p.Wi = lw[l - 1]; p.Ho = lh[l]; p.Wo = lw[l];
-            add("avgpool_s" + std::to_string(l), 4.0 * B * p.Ho * p.Wo * 4, (double)B * (p.Hi * p.Wi + p.Ho * p.Wo) * 4 * es,
-                [=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
-        }
+        PoolArgs p; p.s1 = s[1]; p.s2 = s[2]; p.s3 = s[3];
+        p.H1 = lh[1]; p.W1 = lw[1]; p.H2 = lh[2]; p.W2 = lw[2]; p.H3 = lh[3]; p.W3 = lw[3];
+        add("pyramid_s2s3", 8.0 * B * lh[1] * lw[1], (double)B * (lh[1] * lw[1] + lh[2] * lw[2] + lh[3] * lw[3]) * 4 * es,
+            [=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
@@ -557,20 +556,41 @@ int build_plan(rvm_ctx* c) {
         }
         T* dwo = abuf((size_t)B * Ho * Wo * exp);
         const int npix = Ho * Wo;
-        const int CG = exp / 8;
-        int PY = std::max(1, 256 / CG);
-        const int target = b.has_se ? 64 : 1024;
-        int ppb = rup(std::max(1, cdiv(npix, target)), PY);
-        const int nblk = cdiv(npix, ppb);
+        // small pyramid levels: LDS-tiled kernel (8 channels x a band of output rows per block);
+        // large ones: direct kernel (channel groups x pixel lanes).
+        const int K = b.dw.K;
+        bool use_lds = Wi <= 128;
+        int band = Ho, nblk = 1, max_rows = 0;
+        if (use_lds) {
+            // shrink the band until the chip has >= ~96 blocks, keep at least 4 output rows
+            while (band > 4 && (exp / 8) * cdiv(Ho, band) * B < 96) band = cdiv(band, 2);
+            auto rows_for = [&](int bd) { return std::min(Hi, (bd - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
+            while (band > 1 && dw_lds_bytes(K, rows_for(band), Wi, (int)es) > 64 * 1024) band = cdiv(band, 2);
+            max_rows = rows_for(band);
+            nblk = cdiv(Ho, band);
+            if (dw_lds_bytes(K, max_rows, Wi, (int)es) > 150 * 1024) use_lds = false;
+        }
+        int ppb = band;
+        if (!use_lds) {
+            int CGB, PYB;
+            dw_block_shape(exp, &CGB, &PYB);
+            // pixel chunks: ~2 pixels per thread; SE layers cap the number of partial-sum rows at 64
+            nblk = std::max(1, cdiv(npix, PYB * 2));
+            if (b.has_se) nblk = std::min(nblk, 64);
+            ppb = cdiv(npix, nblk);
+            nblk = cdiv(npix, ppb);
+        }
         float* partial = b.has_se ? fbuf((size_t)B * nblk * exp) : nullptr;
         {
             DwArgs a; a.x = ex; a.y = dwo; a.w = (const float*)(wb + b.dw.w); a.bias = (const float*)(wb + b.dw.bias);
             a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
             a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
-            const int K = b.dw.K;
             add("mb" + std::to_string(i + 1) + ".dw" + std::to_string(K) + "x" + std::to_string(K),
                 2.0 * B * npix * exp * K * K, (double)B * (Hi * Wi + npix) * exp * es,
-                [=](hipStream_t st, const FrameIO&) { launch_dw<T>(a, B, K, st); });
+                [=](hipStream_t st, const FrameIO&) {
+                    if (use_lds) launch_dw_lds<T>(a, B, K, max_rows, st);
+                    else launch_dw<T>(a, B, K, st);
+                });
         }
         const T* scale = nullptr;
         if (b.has_se) {

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
-    Frag<T> wf[NW], xf[MW], wn_[NW], xn_[MW];
+    constexpr int PF = 3;                                   // operand prefetch depth (K steps)
+    Frag<T> wf[PF][NW], xf[PF][MW];
     auto load_step = [&](int ks, Frag<T>* wo, Frag<T>* xo) {
         const int c = ks * 32 + g * 8;
 #pragma unroll
@@ -136,17 +137,20 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
             }
         }
     };
-    load_step(0, wf, xf);
-    for (int ks = 0; ks < a.KS; ++ks) {
-        if (ks + 1 < a.KS) load_step(ks + 1, wn_, xn_);
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi)
+    for (int p = 0; p < PF; ++p) load_step(min(p, a.KS - 1), wf[p], xf[p]);
+    for (int ks0 = 0; ks0 < a.KS; ks0 += PF) {
 #pragma unroll
-            for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
+        for (int p = 0; p < PF; ++p) {
+            const int ks = ks0 + p;
+            if (ks < a.KS) {
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) wf[ni] = wn_[ni];
+                for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi) xf[mi] = xn_[mi];
+                    for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[p][mi]);
+                if (ks + PF < a.KS) load_step(ks + PF, wf[p], xf[p]);
+            }
+        }
     }
 
     // epilogue: lane holds channels ch..ch+3 of pixel pix
@@ -198,65 +202,175 @@ template void launch_pw<float>(const PwArgs&, int, int, hipStream_t);
 // ------------------------------------------------------------------------------------------
 // Depthwise k x k conv (+folded BN, activation, optional squeeze-excite partial sums).
 // Replaces torchvision InvertedResidual's depthwise ConvBNActivation and the avg-pool half
-// of SqueezeExcitation (mobilenetv3.py:39-58).  Block = (C/8 channel groups) x PY pixels;
-// a thread keeps one 8-channel group, so SE sums reduce deterministically through LDS.
+// of SqueezeExcitation (mobilenetv3.py:39-58).  Block = (<=32 channel groups of 8) x PY pixel
+// lanes; grid = (channel-group blocks, pixel chunks, images).  Taps are branch-free (clamped
+// address + 0/1 mask) so all k*k loads of a pixel are in flight together.  A thread keeps one
+// 8-channel group, so the SE sums reduce deterministically: registers -> LDS -> one partial
+// row per pixel chunk.
 // ------------------------------------------------------------------------------------------
 template <typename T, int K>
-__global__ void dw_conv(DwArgs a) {
+__global__ __launch_bounds__(256) void dw_conv(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];
-    const int cg = threadIdx.x, py = threadIdx.y, PY = blockDim.y, n = blockIdx.y;
-    const int c = cg * 8;
+    const int cgl = threadIdx.x, CGB = blockDim.x, py = threadIdx.y, PY = blockDim.y, n = blockIdx.z;
+    const int cg = blockIdx.x * CGB + cgl;
+    const bool cvalid = cg * 8 < a.C;
+    const int c = cvalid ? cg * 8 : 0;
     const int npix = a.Ho * a.Wo;
-    const int pbeg = blockIdx.x * a.ppb;
+    const int pbeg = blockIdx.y * a.ppb;
     const int pend = min(pbeg + a.ppb, npix);
-    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.C;
-    T* yb = (T*)a.y + (size_t)n * npix * a.C;
+    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.C + c;
+    T* yb = (T*)a.y + (size_t)n * npix * a.C + c;
+    const float* wb = a.w + c;
     const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
     f32x4 ps0 = f32x4{0, 0, 0, 0}, ps1 = ps0;
     for (int p = pbeg + py; p < pend; p += PY) {
         const int oy = p / a.Wo, ox = p - oy * a.Wo;
         f32x4 a0 = b0, a1 = b1;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {                   // one tap row (K loads + weights) in flight at a time
             const int iy = oy * a.stride - a.pad + ky * a.dil;
-            if (iy < 0 || iy >= a.Hi) continue;
+            const int iyc = min(max(iy, 0), a.Hi - 1);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const int ix = ox * a.stride - a.pad + kx * a.dil;
-                if (ix < 0 || ix >= a.Wi) continue;
-                F8 v = ld8f(xb + ((size_t)iy * a.Wi + ix) * a.C + c);
-                const float* wp = a.w + (ky * K + kx) * a.C + c;
-                a0 += v.lo * *(const f32x4*)wp;
-                a1 += v.hi * *(const f32x4*)(wp + 4);
+                const int ixc = min(max(ix, 0), a.Wi - 1);
+                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+                F8 v = ld8f(xb + ((size_t)iyc * a.Wi + ixc) * a.C);
+                const float* wp = wb + (ky * K + kx) * a.C;
+                a0 += (v.lo * m) * *(const f32x4*)wp;
+                a1 += (v.hi * m) * *(const f32x4*)(wp + 4);
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a0[r] = act_f(a0[r], a.act); a1[r] = act_f(a1[r], a.act); }
-        F8 o; o.lo = a0; o.hi = a1;
-        st8f(yb + (size_t)p * a.C + c, o);
+        if (cvalid) {
+            F8 o; o.lo = a0; o.hi = a1;
+            st8f(yb + (size_t)p * a.C, o);
+        }
         ps0 += a0; ps1 += a1;
     }
     if (a.pool) {
-        *(f32x4*)(red + py * a.C + c) = ps0;
-        *(f32x4*)(red + py * a.C + c + 4) = ps1;
+        const int RS = CGB * 8;
+        *(f32x4*)(red + py * RS + cgl * 8) = ps0;
+        *(f32x4*)(red + py * RS + cgl * 8 + 4) = ps1;
         __syncthreads();
-        if (py == 0) {
+        if (py == 0 && cvalid) {
             for (int q = 1; q < PY; ++q) {
-                ps0 += *(const f32x4*)(red + q * a.C + c);
-                ps1 += *(const f32x4*)(red + q * a.C + c + 4);
+                ps0 += *(const f32x4*)(red + q * RS + cgl * 8);
+                ps1 += *(const f32x4*)(red + q * RS + cgl * 8 + 4);
             }
-            float* o = a.pool + ((size_t)n * a.nblk + blockIdx.x) * a.C + c;
+            float* o = a.pool + ((size_t)n * a.nblk + blockIdx.y) * a.C + c;
             *(f32x4*)o = ps0;
             *(f32x4*)(o + 4) = ps1;
         }
     }
 }
 
+// LDS-tiled depthwise conv for the small pyramid levels.  A block owns 8 channels and a band of
+// output rows: it stages every input row the band needs (full width, 8 channels) and the k*k
+// weights of its channels into LDS with batched loads, then each thread produces output pixels
+// from LDS only.  At 17x30 a band is the whole image, so the squeeze-excite sum of the block's
+// channels is complete in one block (one partial row).
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dw_conv_lds(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int c = blockIdx.x * 8;
+    const int r0 = blockIdx.y * a.ppb;                                  // ppb = output rows per band here
+    const int r1 = min(r0 + a.ppb, a.Ho);
+    const int in_lo = max(r0 * a.stride - a.pad, 0);
+    const int in_hi = min((r1 - 1) * a.stride - a.pad + (K - 1) * a.dil, a.Hi - 1);
+    const int nrows = in_hi - in_lo + 1;
+    float* wl = (float*)dsm;                                            // [K*K][8]
+    float* red = wl + K * K * 8;                                        // [4 waves][8]
+    T* tile = (T*)(red + 32);                                           // [nrows][Wi][8]
+    const T* xb = (const T*)a.x + ((size_t)n * a.Hi + in_lo) * a.Wi * a.C + c;
+    // ---- stage: 2 quads per pixel, 8 items per thread per round
+    {
+        const int total = nrows * a.Wi * 2;
+        for (int it0 = tid; it0 < total; it0 += 256 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = min(it0 + u * 256, total - 1);
+                v[u] = ld4f(xb + (size_t)(it >> 1) * a.C + (it & 1) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = it0 + u * 256;
+                if (it < total) st4f(tile + (size_t)it * 4, v[u]);
+            }
+        }
+        for (int i = tid; i < K * K * 8; i += 256) wl[i] = a.w[(size_t)(i >> 3) * a.C + c + (i & 7)];
+    }
+    __syncthreads();
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    f32x4 ps0 = f32x4{0, 0, 0, 0}, ps1 = ps0;
+    const int npx = (r1 - r0) * a.Wo;
+    T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C + c;
+    for (int p = tid; p < npx; p += 256) {
+        const int oyl = p / a.Wo, ox = p - oyl * a.Wo;
+        const int iy0 = (r0 + oyl) * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        f32x4 a0 = b0, a1 = b1;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = iy0 + ky * a.dil;
+            const int iyc = min(max(iy, in_lo), in_hi);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ix0 + kx * a.dil;
+                const int ixc = min(max(ix, 0), a.Wi - 1);
+                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+                const F8 v = ld8f(tile + ((size_t)(iyc - in_lo) * a.Wi + ixc) * 8);
+                const float* wp = wl + (ky * K + kx) * 8;
+                a0 += (v.lo * m) * *(const f32x4*)wp;
+                a1 += (v.hi * m) * *(const f32x4*)(wp + 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = act_f(a0[r], a.act); a1[r] = act_f(a1[r], a.act); }
+        F8 o; o.lo = a0; o.hi = a1;
+        st8f(yb + (size_t)p * a.C, o);
+        ps0 += a0; ps1 += a1;
+    }
+    if (a.pool) {
+        // wave reduce (fixed butterfly order), then 4 waves through LDS
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ps0[r] += __shfl_xor(ps0[r], m); ps1[r] += __shfl_xor(ps1[r], m); }
+        }
+        const int wave = tid >> 6, lane = tid & 63;
+        if (lane == 0) { *(f32x4*)(red + wave * 8) = ps0; *(f32x4*)(red + wave * 8 + 4) = ps1; }
+        __syncthreads();
+        if (tid < 8) {
+            const float sum = ((red[tid] + red[8 + tid]) + red[16 + tid]) + red[24 + tid];
+            a.pool[((size_t)n * a.nblk + blockIdx.y) * a.C + c + tid] = sum;
+        }
+    }
+}
+size_t dw_lds_bytes(int K, int nrows, int Wi, int es) { return (size_t)(K * K * 8 + 32) * 4 + (size_t)nrows * Wi * 8 * es; }
+template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s) {
+    dim3 grid(a.C / 8, a.nblk, N);
+    const size_t lds = dw_lds_bytes(K, max_rows, a.Wi, sizeof(T));
+    if (K == 3) hipLaunchKernelGGL((dw_conv_lds<T, 3>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dw_conv_lds<T, 5>), grid, dim3(256), lds, s, a);
+}
+template void launch_dw_lds<f16>(const DwArgs&, int, int, int, hipStream_t);
+template void launch_dw_lds<float>(const DwArgs&, int, int, int, hipStream_t);
+
+void dw_block_shape(int C, int* cgb, int* pyb) {
+    const int CG = C / 8;
+    const int ncb = (CG + 31) / 32;
+    *cgb = (CG + ncb - 1) / ncb;
+    *pyb = 256 / *cgb;
+}
 template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s) {
-    const int CG = a.C / 8;
-    int PY = 256 / CG; if (PY < 1) PY = 1;
-    dim3 block(CG, PY), grid(a.nblk, N);
-    size_t lds = a.pool ? (size_t)PY * a.C * sizeof(float) : 0;
+    int CGB, PYB;
+    dw_block_shape(a.C, &CGB, &PYB);
+    const int ncb = (a.C / 8 + CGB - 1) / CGB;
+    dim3 block(CGB, PYB), grid(ncb, a.nblk, N);
+    size_t lds = a.pool ? (size_t)PYB * CGB * 8 * sizeof(float) : 0;
     if (K == 3) hipLaunchKernelGGL((dw_conv<T, 3>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((dw_conv<T, 5>), grid, block, lds, s, a);
 }
@@ -273,26 +387,40 @@ __global__ __launch_bounds__(256) void gemv_act(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int n = blockIdx.y;
     for (int i = threadIdx.x; i < a.I; i += 256) {
+        const float* xp = a.xin + (size_t)n * a.nparts * a.part_stride + i;
         float s = 0.f;
-        for (int p = 0; p < a.nparts; ++p) s += a.xin[((size_t)n * a.nparts + p) * a.part_stride + i];
+        int p = 0;
+        for (; p + 8 <= a.nparts; p += 8) {          // 8 independent loads in flight, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = xp[(size_t)(p + j) * a.part_stride];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; p < a.nparts; ++p) s += xp[(size_t)p * a.part_stride];
         xs[i] = s * a.xscale;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = 0; k < a.opw; ++k) {
-        const int o = (blockIdx.x * 4 + wave) * a.opw + k;
-        if (o >= a.O) break;
-        const T* wr = (const T*)a.w + (size_t)o * a.I;
-        float s = 0.f;
-        for (int i = lane * 8; i < a.I; i += 512) {
-            F8 wv = ld8f(wr + i);
-            const f32x4 x0 = *(const f32x4*)(xs + i), x1 = *(const f32x4*)(xs + i + 4);
-            s += wv.lo[0] * x0[0] + wv.lo[1] * x0[1] + wv.lo[2] * x0[2] + wv.lo[3] * x0[3]
-               + wv.hi[0] * x1[0] + wv.hi[1] * x1[1] + wv.hi[2] * x1[2] + wv.hi[3] * x1[3];
+    const int o0 = (blockIdx.x * 4 + wave) * a.opw;     // opw <= 4 outputs per wave, rows loaded together
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane * 8; i < a.I; i += 512) {
+        const f32x4 x0 = *(const f32x4*)(xs + i), x1 = *(const f32x4*)(xs + i + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < a.opw && o0 + k < a.O) {
+                F8 wv = ld8f((const T*)a.w + (size_t)(o0 + k) * a.I + i);
+                acc[k] += wv.lo[0] * x0[0] + wv.lo[1] * x0[1] + wv.lo[2] * x0[2] + wv.lo[3] * x0[3]
+                        + wv.hi[0] * x1[0] + wv.hi[1] * x1[1] + wv.hi[2] * x1[2] + wv.hi[3] * x1[3];
+            }
         }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float s = acc[k];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) {
+        const int o = o0 + k;
+        if (lane == 0 && k < a.opw && o < a.O) {
             if (a.bias) s += a.bias[o];
             s = act_f(s, a.act);
             if (a.y_is_T) ((T*)a.y)[(size_t)n * a.O + o] = (T)s;
@@ -321,58 +449,102 @@ template <typename T> size_t conv3_lds_bytes(int MW, int Cpad) {
 template size_t conv3_lds_bytes<f16>(int, int);
 template size_t conv3_lds_bytes<float>(int, int);
 
+// Stage one source of the concatenated conv input into the LDS halo patch.  The (pixel, channel
+// quad) items of the source are walked as one flat index, 8 items per thread per round, with a
+// branch-free body (clamped address + select): 8 (direct) or 32 (bilinear) independent loads are
+// in flight per thread, which is what hides the L2 / Infinity-Cache latency of these tiny tensors.
+template <typename T, bool UP, int PH>
+__device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int coff, int CSL, int n, int y0, int x0,
+                                             int H, int W, int tid) {
+    constexpr int PW = 18, UN = UP ? 4 : 8;
+    const int QN = S.C >> 2;
+    const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16
+    const int total = PH * PW * QN;
+    const bool hf = sizeof(T) == 2 || S.f16;
+    const bool live = S.p != nullptr;
+    const void* base = live ? S.p : (const void*)patch;      // never dereferenced when !live
+    for (int it0 = tid; it0 < total; it0 += 256 * UN) {
+        f32x4 v[UN];
+        int dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int it = min(it0 + u * 256, total - 1);
+            const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
+            const int py = pp / PW, px = pp - py * PW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            dst[u] = (it0 + u * 256 < total) ? pp * CSL + coff + q * 4 : -1;
+            v[u] = f32x4{0, 0, 0, 0};
+            if (live) {
+                if (!UP) {
+                    v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + q * 4, hf);
+                } else {
+                    // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
+                    const float sy = fmaxf(cy * 0.5f - 0.25f, 0.f), sx = fmaxf(cx * 0.5f - 0.25f, 0.f);
+                    const int iy0 = (int)sy, ix0 = (int)sx;
+                    const float ly = sy - iy0, lx = sx - ix0;
+                    const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
+                    const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + q * 4;
+                    const f32x4 v00 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
+                    const f32x4 v01 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
+                    const f32x4 v10 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
+                    const f32x4 v11 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix1) * S.Cs, hf);
+                    v[u] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                }
+            }
+            if (!inb) v[u] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (dst[u] >= 0) st4f(patch + dst[u], v[u]);
+    }
+}
+
 template <typename T, int MW, int NW>
 __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* patch = (T*)smem;
     constexpr int TH = 4 * MW, PH = TH + 2, PW = 18;
+    constexpr int PF = sizeof(T) == 2 ? 8 : 4;              // weight-fragment prefetch depth (K steps)
     const int CSL = a.Cpad + Tr<T>::kLdsPad;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int y0 = ty * TH, x0 = tx * 16, n = blockIdx.z;
     const int H = a.H, W = a.W;
 
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.y * NW;
+    const T* wp[NW];
+    bool nv[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        nv[ni] = (nt0 + ni) < a.NT;
+        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
+    }
+    // start streaming the first weight fragments before the patch is staged
+    Frag<T> wf[PF][NW];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)min(p, a.KS - 1) * 512);
+
     // ---- stage the (TH+2) x 18 halo patch of the concatenated input ----
     {
-        const int QN = a.Cpad >> 2;
-        const int QL = 1 << a.ql_log2;
-        const int ql = tid & (QL - 1), pl = tid >> a.ql_log2, pstep = 256 >> a.ql_log2;
-        for (int pp = pl; pp < PH * PW; pp += pstep) {
-            const int py = pp / PW, px = pp - py * PW;
-            const int gy = y0 + py - 1, gx = x0 + px - 1;
-            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
-            float sy = fmaxf(gy * 0.5f - 0.25f, 0.f), sx = fmaxf(gx * 0.5f - 0.25f, 0.f);
-            const int iy0 = (int)sy, ix0 = (int)sx;
-            const float ly = sy - iy0, lx = sx - ix0;
-            for (int q = ql; q < QN; q += QL) {
-                int cc = q * 4, s = 0;
-                while (s < a.nsrc && cc >= a.src[s].C) { cc -= a.src[s].C; ++s; }
-                f32x4 v = f32x4{0, 0, 0, 0};
-                if (inb && s < a.nsrc && a.src[s].p) {
-                    const ConvSrc& S = a.src[s];
-                    const bool hf = sizeof(T) == 2 || S.f16;
-                    if (!S.up) {
-                        v = ld4x(S.p, (((size_t)n * H + gy) * W + gx) * S.Cs + cc, hf);
-                    } else {
-                        const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
-                        const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + cc;
-                        f32x4 v00 = ld4x(S.p, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
-                        f32x4 v01 = ld4x(S.p, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
-                        f32x4 v10 = ld4x(S.p, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
-                        f32x4 v11 = ld4x(S.p, b + ((size_t)iy1 * S.Ws + ix1) * S.Cs, hf);
-                        v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-                    }
-                }
-                st4f(patch + pp * CSL + q * 4, v);
-            }
+        int coff = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+            if (a.src[s].up) stage_source<T, true, PH>(patch, a.src[s], coff, CSL, n, y0, x0, H, W, tid);
+            else stage_source<T, false, PH>(patch, a.src[s], coff, CSL, n, y0, x0, H, W, tid);
+            coff += a.src[s].C;
+        }
+        if (coff < a.Cpad) {                                // zero the pad channels (weights there are 0, keep them finite)
+            for (int pp = tid; pp < PH * PW; pp += 256)
+                for (int cch = coff; cch < a.Cpad; cch += 4) st4f(patch + pp * CSL + cch, f32x4{0, 0, 0, 0});
         }
     }
     __syncthreads();
 
     // ---- implicit GEMM ----
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int nt0 = blockIdx.y * NW;
     const int NQ8 = a.Cpad >> 3;
     int tap = 0, c8 = g;
     while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
@@ -383,34 +555,29 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
-    const T* wp[NW];
-    bool nv[NW];
+    Frag<T> xf[MW];
+    for (int ks0 = 0; ks0 < a.KS; ks0 += PF) {
 #pragma unroll
-    for (int ni = 0; ni < NW; ++ni) {
-        nv[ni] = (nt0 + ni) < a.NT;
-        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
-    }
-    Frag<T> wf[NW], wn_[NW], xf[MW];
+        for (int p = 0; p < PF; ++p) {
+            const int ks = ks0 + p;
+            if (ks < a.KS) {
+                const int tp = min(tap, 8);                 // K tail: weights are zero there, keep the read in-bounds
+                const int dy = (tp * 11) >> 5, dx = tp - dy * 3;
+                const T* pb = patch + ((wave + dy) * PW + l15 + dx) * CSL + c8 * 8;
 #pragma unroll
-    for (int ni = 0; ni < NW; ++ni) wf[ni].load(wp[ni]);
-    for (int ks = 0; ks < a.KS; ++ks) {
-        if (ks + 1 < a.KS) {
+                for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi) * PW * CSL);
 #pragma unroll
-            for (int ni = 0; ni < NW; ++ni) wn_[ni].load(wp[ni] + (size_t)(ks + 1) * 512);
+                for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[mi]);
+                if (ks + PF < a.KS) {
+#pragma unroll
+                    for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)(ks + PF) * 512);
+                }
+                c8 += 4;
+                while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+            }
         }
-        const int tp = min(tap, 8);                 // K tail: weights are zero there, keep the read in-bounds
-        const int dy = (tp * 11) >> 5, dx = tp - dy * 3;
-        const T* pb = patch + ((wave + dy) * PW + l15 + dx) * CSL + c8 * 8;
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi) * PW * CSL);
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NW; ++ni) wf[ni] = wn_[ni];
-        c8 += 4;
-        while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
     }
 
     // ---- epilogue ----
@@ -535,59 +702,90 @@ template void launch_stem<float>(const StemArgs&, int, hipStream_t);
 // bilinear coordinates (model/model.py:80-81: align_corners=False,
 // recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
 // ------------------------------------------------------------------------------------------
+// One thread produces a 2x2 block of s0 and the s1 pixel above it (first level of the decoder's
+// AvgPool pyramid, decoder.py:33-36: 2x2, ceil_mode, count_include_pad=False).
 template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (p >= a.h * a.w) return;
-    const int oy = p / a.w, ox = p - oy * a.w;
-    float sy = a.scale_y * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    float sx = a.scale_x * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-    int y0 = (int)sy, x0 = (int)sx;
-    if (y0 > a.H - 1) y0 = a.H - 1;
-    if (x0 > a.W - 1) x0 = a.W - 1;
-    const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
-    const float ly = sy - y0, lx = sx - x0;
+    if (p >= a.h1 * a.w1) return;
+    const int py = p / a.w1, px = p - py * a.w1;
     const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * a.H * a.W;
-    f32x4 o;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const TIO* pl = sp + (size_t)c * a.H * a.W;
-        const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
-        const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
-        o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-        o[c] = (float)(T)o[c];
-    }
-    o[3] = (o[0] + o[1] + o[2]) / 3.f;
-    st4f((T*)a.s0 + ((size_t)n * a.h * a.w + p) * 4, o);
-}
-template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
-    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((downsample<T, T>), dim3((a.h * a.w + 255) / 256, N), dim3(256), 0, s, a);
-}
-template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
-template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
-
-// 2x2 stride-2 average pool, ceil_mode, count_include_pad=False (decoder.py:33) on NHWC4.
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool2(PoolArgs a) {
-    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (p >= a.Ho * a.Wo) return;
-    const int oy = p / a.Wo, ox = p - oy * a.Wo;
-    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * 4;
-    f32x4 s = f32x4{0, 0, 0, 0};
+    const size_t plane = (size_t)a.H * a.W;
+    f32x4 acc = f32x4{0, 0, 0, 0};
     int cnt = 0;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const int iy = 2 * oy + dy, ix = 2 * ox + dx;
-            if (iy < a.Hi && ix < a.Wi) { s += ld4f(xb + ((size_t)iy * a.Wi + ix) * 4); ++cnt; }
+            const int oy = 2 * py + dy, ox = 2 * px + dx;
+            if (oy >= a.h || ox >= a.w) continue;
+            float sy = a.scale_y * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = a.scale_x * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            int y0 = (int)sy, x0 = (int)sx;
+            if (y0 > a.H - 1) y0 = a.H - 1;
+            if (x0 > a.W - 1) x0 = a.W - 1;
+            const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
+            const float ly = sy - y0, lx = sx - x0;
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const TIO* pl = sp + c * plane;
+                const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
+                const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
+                o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                o[c] = (float)(T)o[c];
+            }
+            o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
+            st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
+            acc += o; ++cnt;
         }
-    s = s / (float)cnt;
-    st4f((T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 4, s);
+    acc = acc / (float)cnt;
+    st4f((T*)a.s1 + ((size_t)n * a.h1 * a.w1 + p) * 4, acc);
+}
+template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
+    const dim3 grid((a.h1 * a.w1 + 255) / 256, N);
+    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((downsample<T, T>), grid, dim3(256), 0, s, a);
+}
+template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
+template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
+
+// Levels 2 and 3 of the pyramid in one launch: a thread owns one s3 pixel, averages the (up to)
+// 4x4 s1 pixels under it into 2x2 s2 pixels, stores them, and averages those into s3.
+template <typename T>
+__global__ __launch_bounds__(256) void pyramid23(PoolArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (p >= a.H3 * a.W3) return;
+    const int y3 = p / a.W3, x3 = p - y3 * a.W3;
+    const T* s1 = (const T*)a.s1 + (size_t)n * a.H1 * a.W1 * 4;
+    f32x4 acc3 = f32x4{0, 0, 0, 0};
+    int cnt3 = 0;
+#pragma unroll
+    for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+        for (int ex = 0; ex < 2; ++ex) {
+            const int y2 = 2 * y3 + ey, x2 = 2 * x3 + ex;
+            if (y2 >= a.H2 || x2 >= a.W2) continue;
+            f32x4 acc = f32x4{0, 0, 0, 0};
+            int cnt = 0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int iy = 2 * y2 + dy, ix = 2 * x2 + dx;
+                    if (iy < a.H1 && ix < a.W1) { acc += ld4f(s1 + ((size_t)iy * a.W1 + ix) * 4); ++cnt; }
+                }
+            acc = acc / (float)cnt;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = (float)(T)acc[c];
+            st4f((T*)a.s2 + (((size_t)n * a.H2 + y2) * a.W2 + x2) * 4, acc);
+            acc3 += acc; ++cnt3;
+        }
+    acc3 = acc3 / (float)cnt3;
+    st4f((T*)a.s3 + ((size_t)n * a.H3 * a.W3 + p) * 4, acc3);
 }
 template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((avgpool2<T>), dim3((a.Ho * a.Wo + 255) / 256, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((pyramid23<T>), dim3((a.H3 * a.W3 + 255) / 256, N), dim3(256), 0, s, a);
 }
 template void launch_pool<f16>(const PoolArgs&, int, hipStream_t);
 template void launch_pool<float>(const PoolArgs&, int, hipStream_t);
@@ -854,6 +1052,10 @@ template <typename T, int MW, int NW> static void conv3_attr() {
     (void)hipFuncSetAttribute((const void*)conv3x3<T, MW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void kernels_init() {
+    (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     conv3_attr<f16, 4, 1>(); conv3_attr<f16, 2, 2>(); conv3_attr<f16, 2, 1>(); conv3_attr<f16, 1, 2>(); conv3_attr<f16, 1, 1>();
     conv3_attr<float, 4, 1>(); conv3_attr<float, 2, 2>(); conv3_attr<float, 2, 1>(); conv3_attr<float, 1, 2>(); conv3_attr<float, 1, 1>();
 }
