@@ -27,6 +27,8 @@ from robustvideomatting_amd import MattingNetwork, streams, synthetic   # noqa: 
 WORKLOADS = {
     "hd": dict(H=1080, W=1920, ds=0.25, name="rvm_mobilenetv3 fp16 1x1920x1080 ds=0.25 (BASELINE configs[1])"),
     "4k": dict(H=2160, W=3840, ds=0.125, name="rvm_mobilenetv3 fp16 1x3840x2160 ds=0.125 (BASELINE configs[2])"),
+    "hd_resnet50": dict(H=1080, W=1920, ds=0.25, variant="resnet50",
+                        name="rvm_resnet50 fp16 1x1920x1080 ds=0.25 (BASELINE configs[3])"),
     "small": dict(H=288, W=512, ds=1.0, name="rvm_mobilenetv3 512x288 ds=1 (BASELINE configs[0] shape)"),
 }
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
@@ -46,17 +48,18 @@ def frame_algorithmic_bytes(H, W, h, w, es):
 def cpu_baseline(wl, seconds=15.0):
     """The fp32 CPU oracle (restatement of the reference's PyTorch path) timed on host cores."""
     from oracle import rvm_oracle as O
-    params = synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=0)
+    variant = wl.get("variant", "mobilenetv3")
+    params = synthetic.make_params(variant, "deep_guided_filter", seed=0)
     clip = synthetic.make_clip(2, wl["H"], wl["W"], seed=0)
     rec = [None] * 4
     t0 = time.perf_counter()
-    out = O.forward(params, clip[:, 0], *rec, downsample_ratio=wl["ds"])
+    out = O.forward(params, clip[:, 0], *rec, downsample_ratio=wl["ds"], variant=variant)
     rec = out[2:]
     t_first = time.perf_counter() - t0
     n = int(max(3, min(30, seconds / max(t_first, 1e-3))))
     t0 = time.perf_counter()
     for i in range(n):
-        out = O.forward(params, clip[:, i % 2], *rec, downsample_ratio=wl["ds"])
+        out = O.forward(params, clip[:, i % 2], *rec, downsample_ratio=wl["ds"], variant=variant)
         rec = out[2:]
     dt = time.perf_counter() - t0
     return dict(value=n / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
@@ -95,8 +98,9 @@ def main():
     tdt = torch.float32 if a.dtype == "fp32" else torch.float16
     es = 4 if a.dtype == "fp32" else 2
 
-    model = MattingNetwork("mobilenetv3", "deep_guided_filter").eval()
-    model.load_state_dict(synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=0))
+    variant = wl.get("variant", "mobilenetv3")
+    model = MattingNetwork(variant, "deep_guided_filter").eval()
+    model.load_state_dict(synthetic.make_params(variant, "deep_guided_filter", seed=0))
     model = model.to(dev, tdt)
     model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")

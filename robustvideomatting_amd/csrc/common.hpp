@@ -34,6 +34,8 @@ struct PwArgs {
     void* y; int Cout; int ys;              // out [N][HW][ys]
     float* pool;                            // [N][MT][NT*16] per-m-tile column sums or null
     int HW; int MT; int NT; int act;
+    int act_post;                           // apply `act` after the residual add (resnet bottleneck)
+    int sstride, sHi, sWi, sWo;             // sstride > 1: strided 1x1 (input HxW = sHi x sWi, output width sWo)
 };
 
 // ---- depthwise conv ----------------------------------------------------------------------
@@ -60,7 +62,9 @@ enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
 struct ConvArgs {
     ConvSrc src[4]; int nsrc; int Cpad; int ql_log2;
     const void* w; int KS; int NT; const float* bias;
-    int H, W, tiles_x, epi;
+    int H, W, tiles_x, epi;                 // H, W: OUTPUT size
+    int Hi, Wi;                             // input size of the direct (non-upsampled) sources
+    int CC, nchunks;                        // channel chunk staged per pass (multiple of 8), number of passes
     void* y; int Cout; int ys;              // EPI_RELU
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
@@ -77,6 +81,8 @@ struct StemArgs {
 // ---- resize / pyramid ----------------------------------------------------------------------
 struct DownArgs { const void* src; void* s0; void* s1; int H, W, h, w, h1, w1; float scale_y, scale_x; };
 struct PoolArgs { const void* s1; void* s2; void* s3; int H1, W1, H2, W2, H3, W3; };
+
+struct MaxPoolArgs { const void* x; void* y; int C, Hi, Wi, Ho, Wo; };
 
 // ---- refiner ------------------------------------------------------------------------------
 struct DgfWeights {                          // device blob layout (floats)
@@ -98,14 +104,15 @@ struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; voi
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);
 template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s);
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
-template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, hipStream_t s);
+template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s);
+template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s);
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
-template <typename T> size_t conv3_lds_bytes(int MW, int Cpad);
+template <typename T> size_t conv_lds_bytes(int MW, int KD, int S, int D, int CC);
 void dw_block_shape(int C, int* cgb, int* pyb);
 size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
 template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);

@@ -154,7 +154,8 @@ std::vector<ParamSpec> param_specs(int variant, int refiner) {
 struct PwLayer { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, KS = 0, NT = 0, act = 0; };
 struct DwLayer { size_t w = 0, bias = 0; int C = 0, K = 3, stride = 1, dil = 1, pad = 1, act = 0; };
 struct SeLayer { size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };
-struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0, Cin = 0; };
+struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0, Cin = 0; int KD = 3, geo = 0, CC = 0, nchunks = 1; };
+struct ResBlock { PwLayer c1, c3, ds; Conv3Layer c2; bool has_ds = false; int stride = 1, planes = 0, inpl = 0; };
 struct GruLayer { Conv3Layer ih, hh; int C = 0; };
 struct MbBlock { bool has_expand = false, has_se = false, res = false; PwLayer expand, project; DwLayer dw; SeLayer se; MbRow row; };
 
@@ -178,6 +179,8 @@ struct rvm_ctx {
     char* wdev = nullptr;
     size_t stem_w = 0, stem_b = 0;
     MbBlock mb[15];
+    Conv3Layer res_stem;            // resnet50: conv1 7x7 s2
+    std::vector<ResBlock> res;      // resnet50: 16 bottlenecks
     PwLayer last, aspp1;
     size_t aspp2_w = 0;
     int enc_out = 0, aspp_c = 0, feat[4], dec[4];
@@ -265,13 +268,13 @@ size_t put_floats(rvm_ctx* c, const std::vector<float>& v) {
     return off;
 }
 
-// W[out][in][KK] -> MFMA fragments [NT][KS][64 lanes][8], k = tap*Cpad + packed_channel.
-// out_map[po] / in_map[pc] give the original index or -1 (zero row / column).
+// W[out][in][KK] -> MFMA fragments [NT][KS][64 lanes][8].  kmap[k] = {tap, packed channel} of K
+// index k (tap < 0: zero column); out_map[po] / in_map[pc] give the original index or -1.
+struct KEntry { int tap, pc; };
 void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const std::vector<int>& out_map,
-                const std::vector<int>& in_map, const Affine& af, size_t& w_off, size_t& b_off, int& KS, int& NT) {
-    const int Cpad = (int)in_map.size();
-    const int K = KK * Cpad;
-    KS = cdiv(K, 32);
+                const std::vector<int>& in_map, const std::vector<KEntry>& kmap, const Affine& af,
+                size_t& w_off, size_t& b_off, int& KS, int& NT) {
+    KS = (int)kmap.size() / 32;
     NT = (int)out_map.size() / 16;
     std::vector<float> fr((size_t)NT * KS * 512, 0.f), bias((size_t)NT * 16, 0.f);
     for (int nt = 0; nt < NT; ++nt)
@@ -280,11 +283,11 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
                 const int o = out_map[nt * 16 + (lane & 15)];
                 if (o < 0) continue;
                 for (int j = 0; j < 8; ++j) {
-                    const int k = ks * 32 + 8 * (lane >> 4) + j;
-                    if (k >= K) continue;
-                    const int tap = k / Cpad, i = in_map[k % Cpad];
+                    const KEntry e = kmap[ks * 32 + 8 * (lane >> 4) + j];
+                    if (e.tap < 0) continue;
+                    const int i = in_map[e.pc];
                     if (i < 0) continue;
-                    fr[(((size_t)nt * KS + ks) * 64 + lane) * 8 + j] = W[((size_t)o * Cin + i) * KK + tap] * af.scale[o];
+                    fr[(((size_t)nt * KS + ks) * 64 + lane) * 8 + j] = W[((size_t)o * Cin + i) * KK + e.tap] * af.scale[o];
                 }
             }
     for (size_t po = 0; po < out_map.size(); ++po)
@@ -292,6 +295,21 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
     w_off = c->blob_alloc(fr.size() * c->esize());
     put_elems(c, w_off, fr);
     b_off = put_floats(c, bias);
+}
+// K order of conv_kxk: channel chunks of CC; inside a chunk k = tap * chunk_channels + channel; a
+// chunk's step count is padded to a multiple of 8 when there are several chunks (kernels.hip).
+std::vector<KEntry> conv_kmap(int KK, int Cpad, int CC, int nchunks) {
+    std::vector<KEntry> m;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c_lo = ch * CC, CCc = std::min(CC, Cpad - c_lo);
+        int KSc = cdiv(KK * CCc, 32);
+        if (nchunks > 1) KSc = rup(KSc, 8);
+        for (int k = 0; k < KSc * 32; ++k) {
+            if (k < KK * CCc) m.push_back(KEntry{k / CCc, c_lo + k % CCc});
+            else m.push_back(KEntry{-1, 0});
+        }
+    }
+    return m;
 }
 
 std::vector<int> iota_map(int n, int padded) {
@@ -304,15 +322,20 @@ bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, in
     auto W = c->P(wname);
     if (!W) { g_err = "missing parameter " + wname; return false; }
     L.Cin = Cin; L.Cout = Cout; L.act = act;
-    pack_frags(c, *W, Cin, 1, iota_map(Cout, rup(Cout, 16)), iota_map(Cin, rup(Cin, 8)), af, L.w, L.bias, L.KS, L.NT);
+    const int Cp = rup(Cin, 8);
+    pack_frags(c, *W, Cin, 1, iota_map(Cout, rup(Cout, 16)), iota_map(Cin, Cp), conv_kmap(1, Cp, Cp, 1), af, L.w, L.bias, L.KS, L.NT);
     return true;
 }
 
 // srcC: channels of each concatenated source as the kernel sees them (multiples of 4);
 // srcOrig: how many of them are real reference channels (the rest, e.g. the gray lane of the
 // NHWC4 image sources, get zero weights).
+size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
+    const int KD = geo == 3 ? 7 : 3, S = (geo == 1 || geo == 3) ? 2 : 1, D = geo == 2 ? 2 : 1;
+    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, KD, S, D, CC) : conv_lds_bytes<float>(MW, KD, S, D, CC);
+}
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
-                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L) {
+                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0) {
     auto W = c->P(wname);
     if (!W) { g_err = "missing parameter " + wname; return false; }
     int tot = 0, cin = 0;
@@ -324,8 +347,16 @@ bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout
         for (int k = 0; k < srcOrig[s]; ++k) in_map[pc + k] = oc + k;
         pc += srcC[s]; oc += srcOrig[s];
     }
-    L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin;
-    pack_frags(c, *W, cin, 9, out_map, in_map, af, L.w, L.bias, L.KS, L.NT);
+    L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin; L.geo = geo; L.KD = geo == 3 ? 7 : 3;
+    // one pass if the whole-channel halo patch fits comfortably, else channel chunks of <= 64 KiB
+    L.CC = L.Cpad; L.nchunks = 1;
+    if (conv_lds(c, 1, geo, L.Cpad) > 96 * 1024) {
+        int cc = L.Cpad;
+        while (cc > 8 && conv_lds(c, 1, geo, cc) > 64 * 1024) cc -= 8;
+        L.CC = cc; L.nchunks = cdiv(L.Cpad, cc);
+    }
+    pack_frags(c, *W, cin, L.KD * L.KD, out_map, in_map, conv_kmap(L.KD * L.KD, L.Cpad, L.CC, L.nchunks), af,
+               L.w, L.bias, L.KS, L.NT);
     return true;
 }
 
@@ -352,60 +383,95 @@ int finalize_impl(rvm_ctx* c) {
         if (!c->P(s.name)) return fail("rvm_finalize: parameter not set: " + s.name);
     }
     c->blob.clear();
-    if (c->variant != RVM_VARIANT_MOBILENETV3) return fail("rvm_finalize: resnet50 encoder is not implemented yet");
-    c->enc_out = 960; c->aspp_c = 128;
-    { int f[4] = {16, 24, 40, 128}, d[4] = {80, 40, 32, 16}; memcpy(c->feat, f, sizeof f); memcpy(c->dec, d, sizeof d); }
     Affine af;
-    // stem
-    {
-        auto W = c->P("backbone.features.0.0.weight");
-        if (!bn_fold(c, "backbone.features.0.1", 16, 1e-3f, af)) return 1;
-        std::vector<float> w(27 * 16);
-        for (int o = 0; o < 16; ++o)
-            for (int ci = 0; ci < 3; ++ci)
-                for (int t = 0; t < 9; ++t) w[(t * 3 + ci) * 16 + o] = (*W)[(o * 3 + ci) * 9 + t] * af.scale[o];
-        c->stem_w = put_floats(c, w);
-        c->stem_b = put_floats(c, af.shift);
-    }
-    for (int i = 0; i < 15; ++i) {
-        MbBlock& b = c->mb[i];
-        const MbRow& r = kMbRows[i];
-        b.row = r; b.has_expand = r.exp != r.cin; b.has_se = r.se; b.res = (r.stride == 1 && r.cin == r.cout);
-        std::string p = "backbone.features." + std::to_string(i + 1) + ".block.";
-        int j = 0;
-        if (b.has_expand) {
-            if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
-            if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.cin, r.exp, r.act, b.expand)) return 1;
-            ++j;
-        }
+    if (c->variant == RVM_VARIANT_MOBILENETV3) {
+        c->enc_out = 960; c->aspp_c = 128;
+        { int f[4] = {16, 24, 40, 128}, d[4] = {80, 40, 32, 16}; memcpy(c->feat, f, sizeof f); memcpy(c->dec, d, sizeof d); }
+        // stem
         {
-            auto W = c->P(p + std::to_string(j) + ".0.weight");
-            if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
-            const int KK = r.k * r.k;
-            std::vector<float> w((size_t)KK * r.exp);
-            for (int ch = 0; ch < r.exp; ++ch)
-                for (int t = 0; t < KK; ++t) w[(size_t)t * r.exp + ch] = (*W)[(size_t)ch * KK + t] * af.scale[ch];
-            b.dw.w = put_floats(c, w);
-            b.dw.bias = put_floats(c, af.shift);
-            b.dw.C = r.exp; b.dw.K = r.k; b.dw.dil = r.dil; b.dw.stride = r.dil > 1 ? 1 : r.stride;
-            b.dw.pad = (r.k - 1) / 2 * r.dil; b.dw.act = r.act;
-            ++j;
+            auto W = c->P("backbone.features.0.0.weight");
+            if (!bn_fold(c, "backbone.features.0.1", 16, 1e-3f, af)) return 1;
+            std::vector<float> w(27 * 16);
+            for (int o = 0; o < 16; ++o)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int t = 0; t < 9; ++t) w[(t * 3 + ci) * 16 + o] = (*W)[(o * 3 + ci) * 9 + t] * af.scale[o];
+            c->stem_w = put_floats(c, w);
+            c->stem_b = put_floats(c, af.shift);
         }
-        if (b.has_se) {
-            const int S = se_squeeze(r.exp);
-            std::string q = p + std::to_string(j);
-            b.se.C = r.exp; b.se.S = S;
-            b.se.w1 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w1, *c->P(q + ".fc1.weight"));
-            b.se.b1 = put_floats(c, *c->P(q + ".fc1.bias"));
-            b.se.w2 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w2, *c->P(q + ".fc2.weight"));
-            b.se.b2 = put_floats(c, *c->P(q + ".fc2.bias"));
-            ++j;
+        for (int i = 0; i < 15; ++i) {
+            MbBlock& b = c->mb[i];
+            const MbRow& r = kMbRows[i];
+            b.row = r; b.has_expand = r.exp != r.cin; b.has_se = r.se; b.res = (r.stride == 1 && r.cin == r.cout);
+            std::string p = "backbone.features." + std::to_string(i + 1) + ".block.";
+            int j = 0;
+            if (b.has_expand) {
+                if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
+                if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.cin, r.exp, r.act, b.expand)) return 1;
+                ++j;
+            }
+            {
+                auto W = c->P(p + std::to_string(j) + ".0.weight");
+                if (!bn_fold(c, p + std::to_string(j) + ".1", r.exp, 1e-3f, af)) return 1;
+                const int KK = r.k * r.k;
+                std::vector<float> w((size_t)KK * r.exp);
+                for (int ch = 0; ch < r.exp; ++ch)
+                    for (int t = 0; t < KK; ++t) w[(size_t)t * r.exp + ch] = (*W)[(size_t)ch * KK + t] * af.scale[ch];
+                b.dw.w = put_floats(c, w);
+                b.dw.bias = put_floats(c, af.shift);
+                b.dw.C = r.exp; b.dw.K = r.k; b.dw.dil = r.dil; b.dw.stride = r.dil > 1 ? 1 : r.stride;
+                b.dw.pad = (r.k - 1) / 2 * r.dil; b.dw.act = r.act;
+                ++j;
+            }
+            if (b.has_se) {
+                const int S = se_squeeze(r.exp);
+                std::string q = p + std::to_string(j);
+                b.se.C = r.exp; b.se.S = S;
+                b.se.w1 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w1, *c->P(q + ".fc1.weight"));
+                b.se.b1 = put_floats(c, *c->P(q + ".fc1.bias"));
+                b.se.w2 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w2, *c->P(q + ".fc2.weight"));
+                b.se.b2 = put_floats(c, *c->P(q + ".fc2.bias"));
+                ++j;
+            }
+            if (!bn_fold(c, p + std::to_string(j) + ".1", r.cout, 1e-3f, af)) return 1;
+            if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.exp, r.cout, ACT_NONE, b.project)) return 1;
         }
-        if (!bn_fold(c, p + std::to_string(j) + ".1", r.cout, 1e-3f, af)) return 1;
-        if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.exp, r.cout, ACT_NONE, b.project)) return 1;
+        if (!bn_fold(c, "backbone.features.16.1", 960, 1e-3f, af)) return 1;
+        if (!pack_pw(c, "backbone.features.16.0.weight", af, 160, 960, ACT_HSWISH, c->last)) return 1;
+    } else {
+        // ResNet50 (reference model/resnet.py:5-33; torchvision Bottleneck v1.5, stride on the 3x3,
+        // replace_stride_with_dilation=[F,F,T]); BN eps 1e-5, no input normalisation.
+        c->enc_out = 2048; c->aspp_c = 256;
+        { int f[4] = {64, 256, 512, 256}, d[4] = {128, 64, 32, 16}; memcpy(c->feat, f, sizeof f); memcpy(c->dec, d, sizeof d); }
+        if (!bn_fold(c, "backbone.bn1", 64, 1e-5f, af)) return 1;
+        if (!pack_conv3(c, "backbone.conv1.weight", af, 64, iota_map(64, 64), {4}, {3}, c->res_stem, 3)) return 1;
+        c->res.clear();
+        const int nblk[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+        int inpl = 64, dilation = 1;
+        for (int l = 0; l < 4; ++l) {
+            int stride = l == 0 ? 1 : 2;
+            const int prev_dil = dilation;
+            if (l == 3) { dilation *= stride; stride = 1; }
+            for (int b = 0; b < nblk[l]; ++b) {
+                ResBlock R;
+                R.planes = planes[l]; R.inpl = inpl; R.stride = b == 0 ? stride : 1; R.has_ds = b == 0;
+                const int d = b == 0 ? prev_dil : dilation;
+                const std::string p = "backbone.layer" + std::to_string(l + 1) + "." + std::to_string(b);
+                if (!bn_fold(c, p + ".bn1", planes[l], 1e-5f, af)) return 1;
+                if (!pack_pw(c, p + ".conv1.weight", af, inpl, planes[l], ACT_RELU, R.c1)) return 1;
+                if (!bn_fold(c, p + ".bn2", planes[l], 1e-5f, af)) return 1;
+                const int geo = R.stride == 2 ? 1 : (d == 2 ? 2 : 0);
+                if (!pack_conv3(c, p + ".conv2.weight", af, planes[l], iota_map(planes[l], planes[l]), {planes[l]}, {planes[l]}, R.c2, geo)) return 1;
+                if (!bn_fold(c, p + ".bn3", planes[l] * 4, 1e-5f, af)) return 1;
+                if (!pack_pw(c, p + ".conv3.weight", af, planes[l], planes[l] * 4, ACT_RELU, R.c3)) return 1;
+                if (R.has_ds) {
+                    if (!bn_fold(c, p + ".downsample.1", planes[l] * 4, 1e-5f, af)) return 1;
+                    if (!pack_pw(c, p + ".downsample.0.weight", af, inpl, planes[l] * 4, ACT_NONE, R.ds)) return 1;
+                }
+                c->res.push_back(R);
+                inpl = planes[l] * 4;
+            }
+        }
     }
-    if (!bn_fold(c, "backbone.features.16.1", 960, 1e-3f, af)) return 1;
-    if (!pack_pw(c, "backbone.features.16.0.weight", af, 160, 960, ACT_HSWISH, c->last)) return 1;
     // LR-ASPP
     if (!bn_fold(c, "aspp.aspp1.1", c->aspp_c, 1e-5f, af)) return 1;
     if (!pack_pw(c, "aspp.aspp1.0.weight", af, c->enc_out, c->aspp_c, ACT_RELU, c->aspp1)) return 1;
@@ -518,9 +584,11 @@ int build_plan(rvm_ctx* c) {
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
+    struct PwX { int act_post = 0, sstride = 1, sHi = 0, sWi = 0, sWo = 0; };
     auto pw = [&](const std::string& name, const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
-                  const float* out_scale, float* pool) {
+                  const float* out_scale, float* pool, PwX ex = PwX()) {
         PwArgs a; memset(&a, 0, sizeof a);
+        a.act_post = ex.act_post; a.sstride = ex.sstride; a.sHi = ex.sHi; a.sWi = ex.sWi; a.sWo = ex.sWo;
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
@@ -530,97 +598,186 @@ int build_plan(rvm_ctx* c) {
             [=](hipStream_t st, const FrameIO&) { launch_pw<T>(a, B, cfg, st); });
     };
 
-    // ---- encoder (mobilenetv3.py:36-60)
-    T* cur = abuf((size_t)B * lh[1] * lw[1] * 16);
-    int curC = 16, lvl = 1;
-    {
-        StemArgs a; a.s0 = s[0]; a.y = cur; a.w = (const float*)(wb + c->stem_w); a.bias = (const float*)(wb + c->stem_b);
-        a.Hi = lh[0]; a.Wi = lw[0]; a.Ho = lh[1]; a.Wo = lw[1];
-        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-        for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
-        add("stem_conv3x3s2", 2.0 * B * a.Ho * a.Wo * 27 * 16, (double)B * (a.Hi * a.Wi * 4 + a.Ho * a.Wo * 16) * es,
-            [=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
-    }
+    // KxK conv launcher: (Ho, Wo) output, (Hi, Wi) input of the direct sources
+    auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Ho, int Wo, int Hi, int Wi, int epi,
+                     std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
+        ConvArgs a; memset(&a, 0, sizeof a);
+        a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
+        a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
+        a.CC = L.CC; a.nchunks = L.nchunks;
+        // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
+        int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
+        int MW = 1;
+        const int geo = L.geo;
+        if (geo == 0 && L.nchunks == 1) {
+            const int mws[3] = {4, 2, 1};
+            for (int k = 0; k < 3; ++k) {
+                int m = mws[k];
+                if (NW == 2 && m == 4) continue;
+                if (conv_lds_bytes<T>(m, 3, 1, 1, L.CC) > 150 * 1024) continue;
+                int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, NW) * B;
+                if (blocks >= 256 || m == 1) { MW = m; break; }
+            }
+        } else {
+            NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
+            if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
+        }
+        if (conv_lds(c, MW, geo, L.CC) > 160 * 1024) return fail("conv: input patch does not fit LDS");
+        const double KK = (double)L.KD * L.KD;
+        add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
+            ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es,
+            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, geo, st); });
+        return 0;
+    };
+
     T* f[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 15; ++i) {
-        const MbBlock& b = c->mb[i];
-        const int Hi = lh[lvl], Wi = lw[lvl];
-        const int olvl = b.dw.stride == 2 ? lvl + 1 : lvl;
-        const int Ho = lh[olvl], Wo = lw[olvl];
-        const int exp = b.row.exp;
-        const T* ex = cur;
-        if (b.has_expand) {
-            T* e = abuf((size_t)B * Hi * Wi * exp);
-            pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
-            ex = e;
-        }
-        T* dwo = abuf((size_t)B * Ho * Wo * exp);
-        const int npix = Ho * Wo;
-        // small pyramid levels: LDS-tiled kernel (8 channels x a band of output rows per block);
-        // large ones: direct kernel (channel groups x pixel lanes).
-        const int K = b.dw.K;
-        bool use_lds = Wi <= 128;
-        int band = Ho, nblk = 1, max_rows = 0;
-        if (use_lds) {
-            // shrink the band until the chip has >= ~96 blocks, keep at least 4 output rows
-            while (band > 4 && (exp / 8) * cdiv(Ho, band) * B < 96) band = cdiv(band, 2);
-            auto rows_for = [&](int bd) { return std::min(Hi, (bd - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
-            while (band > 1 && dw_lds_bytes(K, rows_for(band), Wi, (int)es) > 64 * 1024) band = cdiv(band, 2);
-            max_rows = rows_for(band);
-            nblk = cdiv(Ho, band);
-            if (dw_lds_bytes(K, max_rows, Wi, (int)es) > 150 * 1024) use_lds = false;
-        }
-        int ppb = band;
-        if (!use_lds) {
-            int CGB, PYB;
-            dw_block_shape(exp, &CGB, &PYB);
-            // pixel chunks: ~2 pixels per thread; SE layers cap the number of partial-sum rows at 64
-            nblk = std::max(1, cdiv(npix, PYB * 2));
-            if (b.has_se) nblk = std::min(nblk, 64);
-            ppb = cdiv(npix, nblk);
-            nblk = cdiv(npix, ppb);
-        }
-        float* partial = b.has_se ? fbuf((size_t)B * nblk * exp) : nullptr;
-        {
-            DwArgs a; a.x = ex; a.y = dwo; a.w = (const float*)(wb + b.dw.w); a.bias = (const float*)(wb + b.dw.bias);
-            a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
-            a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
-            add("mb" + std::to_string(i + 1) + ".dw" + std::to_string(K) + "x" + std::to_string(K),
-                2.0 * B * npix * exp * K * K, (double)B * (Hi * Wi + npix) * exp * es,
-                [=](hipStream_t st, const FrameIO&) {
-                    if (use_lds) launch_dw_lds<T>(a, B, K, max_rows, st);
-                    else launch_dw<T>(a, B, K, st);
-                });
-        }
-        const T* scale = nullptr;
-        if (b.has_se) {
-            float* hidden = fbuf((size_t)B * b.se.S);
-            T* sc = abuf((size_t)B * exp);
-            GemvArgs g1; memset(&g1, 0, sizeof g1);
-            g1.xin = partial; g1.nparts = nblk; g1.part_stride = exp; g1.xscale = 1.f / (float)npix;
-            g1.w = wb + b.se.w1; g1.bias = (const float*)(wb + b.se.b1); g1.y = hidden; g1.y_is_T = 0;
-            g1.I = exp; g1.O = b.se.S; g1.act = ACT_RELU; g1.opw = 2;
-            GemvArgs g2; memset(&g2, 0, sizeof g2);
-            g2.xin = hidden; g2.nparts = 1; g2.part_stride = b.se.S; g2.xscale = 1.f;
-            g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
-            g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
-            const std::string sn = "mb" + std::to_string(i + 1) + ".se_fc";
-            add(sn + "1", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
-            add(sn + "2", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
-            scale = sc;
-        }
-        T* out = abuf((size_t)B * npix * b.row.cout);
-        pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
-        cur = out; curC = b.row.cout; lvl = olvl;
-        if (i == 0) f[0] = cur;
-        if (i == 2) f[1] = cur;
-        if (i == 5) f[2] = cur;
-    }
     const int HW4 = lh[4] * lw[4];
-    T* f4 = abuf((size_t)B * HW4 * c->enc_out);
     const int MT4 = cdiv(HW4, 16);
-    float* f4pool = fbuf((size_t)B * MT4 * c->last.NT * 16);
-    pw("features16_1x1", c->last, cur, curC, HW4, f4, c->enc_out, nullptr, nullptr, 0, nullptr, f4pool);
+    T* f4 = nullptr;
+    float* f4pool = nullptr;
+    int pool_stride = 0;
+    if (c->variant == RVM_VARIANT_MOBILENETV3) {
+        // ---- encoder (mobilenetv3.py:36-60)
+        T* cur = abuf((size_t)B * lh[1] * lw[1] * 16);
+        int curC = 16, lvl = 1;
+        {
+            StemArgs a; a.s0 = s[0]; a.y = cur; a.w = (const float*)(wb + c->stem_w); a.bias = (const float*)(wb + c->stem_b);
+            a.Hi = lh[0]; a.Wi = lw[0]; a.Ho = lh[1]; a.Wo = lw[1];
+            const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+            for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
+            add("stem_conv3x3s2", 2.0 * B * a.Ho * a.Wo * 27 * 16, (double)B * (a.Hi * a.Wi * 4 + a.Ho * a.Wo * 16) * es,
+                [=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
+        }
+        for (int i = 0; i < 15; ++i) {
+            const MbBlock& b = c->mb[i];
+            const int Hi = lh[lvl], Wi = lw[lvl];
+            const int olvl = b.dw.stride == 2 ? lvl + 1 : lvl;
+            const int Ho = lh[olvl], Wo = lw[olvl];
+            const int exp = b.row.exp;
+            const T* ex = cur;
+            if (b.has_expand) {
+                T* e = abuf((size_t)B * Hi * Wi * exp);
+                pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
+                ex = e;
+            }
+            T* dwo = abuf((size_t)B * Ho * Wo * exp);
+            const int npix = Ho * Wo;
+            // small pyramid levels: LDS-tiled kernel (8 channels x a band of output rows per block);
+            // large ones: direct kernel (channel groups x pixel lanes).
+            const int K = b.dw.K;
+            bool use_lds = Wi <= 128;
+            int band = Ho, nblk = 1, max_rows = 0;
+            if (use_lds) {
+                // shrink the band until the chip has >= ~96 blocks, keep at least 4 output rows
+                while (band > 4 && (exp / 8) * cdiv(Ho, band) * B < 96) band = cdiv(band, 2);
+                auto rows_for = [&](int bd) { return std::min(Hi, (bd - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
+                while (band > 1 && dw_lds_bytes(K, rows_for(band), Wi, (int)es) > 64 * 1024) band = cdiv(band, 2);
+                max_rows = rows_for(band);
+                nblk = cdiv(Ho, band);
+                if (dw_lds_bytes(K, max_rows, Wi, (int)es) > 150 * 1024) use_lds = false;
+            }
+            int ppb = band;
+            if (!use_lds) {
+                int CGB, PYB;
+                dw_block_shape(exp, &CGB, &PYB);
+                // pixel chunks: ~2 pixels per thread; SE layers cap the number of partial-sum rows at 64
+                nblk = std::max(1, cdiv(npix, PYB * 2));
+                if (b.has_se) nblk = std::min(nblk, 64);
+                ppb = cdiv(npix, nblk);
+                nblk = cdiv(npix, ppb);
+            }
+            float* partial = b.has_se ? fbuf((size_t)B * nblk * exp) : nullptr;
+            {
+                DwArgs a; a.x = ex; a.y = dwo; a.w = (const float*)(wb + b.dw.w); a.bias = (const float*)(wb + b.dw.bias);
+                a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
+                a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
+                add("mb" + std::to_string(i + 1) + ".dw" + std::to_string(K) + "x" + std::to_string(K),
+                    2.0 * B * npix * exp * K * K, (double)B * (Hi * Wi + npix) * exp * es,
+                    [=](hipStream_t st, const FrameIO&) {
+                        if (use_lds) launch_dw_lds<T>(a, B, K, max_rows, st);
+                        else launch_dw<T>(a, B, K, st);
+                    });
+            }
+            const T* scale = nullptr;
+            if (b.has_se) {
+                float* hidden = fbuf((size_t)B * b.se.S);
+                T* sc = abuf((size_t)B * exp);
+                GemvArgs g1; memset(&g1, 0, sizeof g1);
+                g1.xin = partial; g1.nparts = nblk; g1.part_stride = exp; g1.xscale = 1.f / (float)npix;
+                g1.w = wb + b.se.w1; g1.bias = (const float*)(wb + b.se.b1); g1.y = hidden; g1.y_is_T = 0;
+                g1.I = exp; g1.O = b.se.S; g1.act = ACT_RELU; g1.opw = 2;
+                GemvArgs g2; memset(&g2, 0, sizeof g2);
+                g2.xin = hidden; g2.nparts = 1; g2.part_stride = b.se.S; g2.xscale = 1.f;
+                g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
+                g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
+                const std::string sn = "mb" + std::to_string(i + 1) + ".se_fc";
+                add(sn + "1", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
+                add(sn + "2", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
+                scale = sc;
+            }
+            T* out = abuf((size_t)B * npix * b.row.cout);
+            pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+            cur = out; curC = b.row.cout; lvl = olvl;
+            if (i == 0) f[0] = cur;
+            if (i == 2) f[1] = cur;
+            if (i == 5) f[2] = cur;
+        }
+        f4 = abuf((size_t)B * HW4 * c->enc_out);
+        pool_stride = c->last.NT * 16;
+        f4pool = fbuf((size_t)B * MT4 * pool_stride);
+        pw("features16_1x1", c->last, cur, curC, HW4, f4, c->enc_out, nullptr, nullptr, 0, nullptr, f4pool);
+    } else {
+        // ---- ResNet50 encoder (resnet.py:20-33)
+        T* x1 = abuf((size_t)B * lh[1] * lw[1] * 64);
+        {
+            const T* s0 = s[0];
+            if (conv3("conv1_7x7s2", c->res_stem, lh[1], lw[1], lh[0], lw[0], EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
+                    a.src[0] = ConvSrc{s0, 4, 4, 0, 0, 0, 0}; a.nsrc = 1; a.y = x1; a.ys = 64;
+                })) return 1;
+        }
+        f[0] = x1;
+        T* cur = abuf((size_t)B * lh[2] * lw[2] * 64);
+        {
+            MaxPoolArgs m; m.x = x1; m.y = cur; m.C = 64; m.Hi = lh[1]; m.Wi = lw[1]; m.Ho = lh[2]; m.Wo = lw[2];
+            add("maxpool3x3s2", 9.0 * B * lh[2] * lw[2] * 64, (double)B * (lh[1] * lw[1] + lh[2] * lw[2]) * 64 * es,
+                [=](hipStream_t st, const FrameIO&) { launch_maxpool<T>(m, B, st); });
+        }
+        int lvl = 2, curC = 64;
+        const int nres = (int)c->res.size();
+        for (int i = 0; i < nres; ++i) {
+            const ResBlock& R = c->res[i];
+            const std::string nm = "res" + std::to_string(i);
+            const int Hi = lh[lvl], Wi = lw[lvl];
+            const int olvl = R.stride == 2 ? lvl + 1 : lvl;
+            const int Ho = lh[olvl], Wo = lw[olvl];
+            T* t1 = abuf((size_t)B * Hi * Wi * R.planes);
+            pw(nm + ".conv1", R.c1, cur, curC, Hi * Wi, t1, R.planes, nullptr, nullptr, 0, nullptr, nullptr);
+            T* t2 = abuf((size_t)B * Ho * Wo * R.planes);
+            {
+                const int P = R.planes;
+                if (conv3(nm + ".conv2", R.c2, Ho, Wo, Hi, Wi, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
+                        a.src[0] = ConvSrc{t1, P, P, 0, 0, 0, 0}; a.nsrc = 1; a.y = t2; a.ys = P;
+                    })) return 1;
+            }
+            const int OC = R.planes * 4;
+            const T* idt = cur; int idtC = curC;
+            if (R.has_ds) {
+                T* d = abuf((size_t)B * Ho * Wo * OC);
+                PwX ex; ex.sstride = R.stride; ex.sHi = Hi; ex.sWi = Wi; ex.sWo = Wo;
+                pw(nm + ".downsample", R.ds, cur, curC, Ho * Wo, d, OC, nullptr, nullptr, 0, nullptr, nullptr, ex);
+                idt = d; idtC = OC;
+            }
+            const bool last = i == nres - 1;
+            T* out = abuf((size_t)B * Ho * Wo * OC);
+            if (last) { pool_stride = R.c3.NT * 16; f4pool = fbuf((size_t)B * MT4 * pool_stride); }
+            PwX ex; ex.act_post = 1;
+            pw(nm + ".conv3", R.c3, t2, R.planes, Ho * Wo, out, OC, nullptr, idt, idtC, nullptr, last ? f4pool : nullptr, ex);
+            cur = out; curC = OC; lvl = olvl;
+            if (i == 2) f[1] = cur;          // layer1 -> f2
+            if (i == 6) f[2] = cur;          // layer2 -> f3
+        }
+        f4 = cur;
+    }
     c->taps["f1"] = Tap{f[0], B, lh[1], lw[1], c->feat[0], c->feat[0], false};
     c->taps["f2"] = Tap{f[1], B, lh[2], lw[2], c->feat[1], c->feat[1], false};
     c->taps["f3"] = Tap{f[2], B, lh[3], lw[3], c->feat[2], c->feat[2], false};
@@ -630,7 +787,7 @@ int build_plan(rvm_ctx* c) {
     float* gate = fbuf((size_t)B * c->aspp_c);
     {
         GemvArgs g; memset(&g, 0, sizeof g);
-        g.xin = f4pool; g.nparts = MT4; g.part_stride = c->last.NT * 16; g.xscale = 1.f / (float)HW4;
+        g.xin = f4pool; g.nparts = MT4; g.part_stride = pool_stride; g.xscale = 1.f / (float)HW4;
         g.w = wb + c->aspp2_w; g.bias = nullptr; g.y = gate; g.y_is_T = 0; g.I = c->enc_out; g.O = c->aspp_c;
         g.act = ACT_SIGMOID; g.opw = 1;
         add("aspp2_gate", 2.0 * B * g.I * g.O, (double)g.I * g.O * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g, B, st); });
@@ -641,40 +798,17 @@ int build_plan(rvm_ctx* c) {
     c->taps["aspp"] = Tap{aspp, B, lh[4], lw[4], AC, AC, false};
 
     // ---- recurrent decoder (decoder.py:17-27)
-    auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Hh, int Ww, int epi, std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
-        ConvArgs a; memset(&a, 0, sizeof a);
-        a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
-        a.H = Hh; a.W = Ww; a.tiles_x = cdiv(Ww, 16); a.epi = epi; a.Cout = L.Cout;
-        int ql = 0; while ((1 << ql) < (L.Cpad >> 2) && ql < 6) ++ql;
-        a.ql_log2 = ql;
-        // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
-        int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
-        const int mws[3] = {4, 2, 1};
-        int MW = 1;
-        for (int k = 0; k < 3; ++k) {
-            int m = mws[k];
-            if (NW == 2 && m == 4) continue;
-            if (conv3_lds_bytes<T>(m, L.Cpad) > 150 * 1024) continue;
-            int blocks = a.tiles_x * cdiv(Hh, 4 * m) * cdiv(L.NT, NW) * B;
-            if (blocks >= 256 || m == 1) { MW = m; break; }
-        }
-        if (conv3_lds_bytes<T>(MW, L.Cpad) > 160 * 1024) return fail("conv3x3: input patch does not fit LDS");
-        add(name, 2.0 * B * Hh * Ww * 9 * L.Cin * L.Cout,
-            ((double)B * Hh * Ww * (L.Cin + L.Cout) + 9.0 * L.Cin * L.Cout) * es,
-            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, st); });
-        return 0;
-    };
     // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
     auto gru = [&](const std::string& name, const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
         const int C = G.C;
         T* rh = abuf((size_t)B * Hh * Ww * C);
         float* z = fbuf((size_t)B * Hh * Ww * C);
-        if (conv3(name + ".ih", G.ih, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3(name + ".ih", G.ih, Hh, Ww, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
                 a.nsrc = 0;
                 a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0, io16}; a.nsrc = 2;
                 a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z; a.state16 = io16;
             })) return 1;
-        if (conv3(name + ".hh", G.hh, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3(name + ".hh", G.hh, Hh, Ww, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0, 0}; a.nsrc = 2;
                 a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx]; a.state16 = io16;
             })) return 1;
@@ -694,7 +828,7 @@ int build_plan(rvm_ctx* c) {
         const T* sl = s[l];
         const int Hs = lh[l + 1], Ws = lw[l + 1];
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
-        if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
                 a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, io16};
                 a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0, 0};
@@ -713,13 +847,13 @@ int build_plan(rvm_ctx* c) {
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
         const T* s0 = s[0];
         const int Hs = lh[1], Ws = lw[1];
-        if (conv3("decode0.conv0", c->out0, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
+        if (conv3("decode0.conv0", c->out0, c->h, c->w, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
                 a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws, io16};
                 a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
-        if (conv3("decode0.conv1", c->out1, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
+        if (conv3("decode0.conv1", c->out1, c->h, c->w, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
                 a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
             })) return 1;
     }

@@ -104,7 +104,12 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     for (int mi = 0; mi < MW; ++mi) {
         int pix = (mt0 + mi) * 16 + l15;
         pv[mi] = (mt0 + mi) < a.MT && pix < a.HW;
-        xp[mi] = (const T*)a.x + ((size_t)n * a.HW + (pv[mi] ? pix : 0)) * a.xs + g * 8;
+        size_t ipix = (size_t)n * a.HW + (pv[mi] ? pix : 0);
+        if (a.sstride > 1) {                                 // 1x1 conv with stride (resnet downsample branch)
+            const int oy = (pv[mi] ? pix : 0) / a.sWo, ox = (pv[mi] ? pix : 0) - oy * a.sWo;
+            ipix = (size_t)n * a.sHi * a.sWi + (size_t)oy * a.sstride * a.sWi + ox * a.sstride;
+        }
+        xp[mi] = (const T*)a.x + ipix * a.xs + g * 8;
     }
     const T* wp[NW];
     bool nv[NW];
@@ -165,11 +170,17 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
         for (int mi = 0; mi < MW; ++mi) {
             const int pix = (mt0 + mi) * 16 + l15;
             f32x4 v = acc[mi][ni] + bias;
+            if (!a.act_post) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+                for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+            }
             const bool ok = pv[mi] && ch < a.Cout;
             if (ok) {
                 if (a.res) v += ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + ch);
+                if (a.act_post) {                            // resnet bottleneck: relu(bn(conv) + identity)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+                }
                 v *= osc;
                 st4f((T*)a.y + ((size_t)n * a.HW + pix) * a.ys + ch, v);
             }
@@ -443,22 +454,31 @@ template void launch_gemv<float>(const GemvArgs&, int, hipStream_t);
 // blend epilogues (:168-172).  K index = tap * Cpad + channel; each 8-channel group of a K
 // step may sit on a different tap.
 // ------------------------------------------------------------------------------------------
-template <typename T> size_t conv3_lds_bytes(int MW, int Cpad) {
-    return (size_t)(4 * MW + 2) * 18 * (Cpad + Tr<T>::kLdsPad) * sizeof(T);
+// Geometry of one block of conv_kxk: TH x 16 output pixels, input halo patch PH x PW.
+template <int MW, int KD, int S, int D> struct ConvGeo {
+    static constexpr int TH = 4 * MW;
+    static constexpr int PH = (TH - 1) * S + (KD - 1) * D + 1;
+    static constexpr int PW = 15 * S + (KD - 1) * D + 1;
+    static constexpr int PAD = (KD - 1) / 2 * D;
+};
+template <typename T> size_t conv_lds_bytes(int MW, int KD, int S, int D, int CC) {
+    const int PH = (4 * MW - 1) * S + (KD - 1) * D + 1, PW = 15 * S + (KD - 1) * D + 1;
+    return (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T);
 }
-template size_t conv3_lds_bytes<f16>(int, int);
-template size_t conv3_lds_bytes<float>(int, int);
+template size_t conv_lds_bytes<f16>(int, int, int, int, int);
+template size_t conv_lds_bytes<float>(int, int, int, int, int);
 
-// Stage one source of the concatenated conv input into the LDS halo patch.  The (pixel, channel
-// quad) items of the source are walked as one flat index, 8 items per thread per round, with a
-// branch-free body (clamped address + select): 8 (direct) or 32 (bilinear) independent loads are
-// in flight per thread, which is what hides the L2 / Infinity-Cache latency of these tiny tensors.
-template <typename T, bool UP, int PH>
-__device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int coff, int CSL, int n, int y0, int x0,
-                                             int H, int W, int tid) {
-    constexpr int PW = 18, UN = UP ? 4 : 8;
-    const int QN = S.C >> 2;
-    const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16
+// Stage channel quads [q_lo, q_lo+q_cnt) of one source of the concatenated conv input into the
+// LDS halo patch (origin gy0,gx0 in source-resolution coordinates).  The (pixel, quad) items are
+// walked as one flat index, several per thread per round, with a branch-free body (clamped
+// address + select): 8 (direct) or 16 (bilinear) independent loads are in flight per thread,
+// which is what hides the L2 / Infinity-Cache latency of these small tensors.
+template <typename T, bool UP, int PH, int PW>
+__device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo, int q_cnt, int dst_c, int CSL, int n,
+                                             int gy0, int gx0, int H, int W, int tid) {
+    constexpr int UN = UP ? 4 : 8;
+    const int QN = q_cnt;
+    const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16 .. see below
     const int total = PH * PW * QN;
     const bool hf = sizeof(T) == 2 || S.f16;
     const bool live = S.p != nullptr;
@@ -471,21 +491,21 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int coff
             const int it = min(it0 + u * 256, total - 1);
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
             const int py = pp / PW, px = pp - py * PW;
-            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            const int gy = gy0 + py, gx = gx0 + px;
             const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            dst[u] = (it0 + u * 256 < total) ? pp * CSL + coff + q * 4 : -1;
+            dst[u] = (it0 + u * 256 < total) ? pp * CSL + dst_c + q * 4 : -1;
             v[u] = f32x4{0, 0, 0, 0};
             if (live) {
                 if (!UP) {
-                    v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + q * 4, hf);
+                    v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + (q_lo + q) * 4, hf);
                 } else {
                     // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
                     const float sy = fmaxf(cy * 0.5f - 0.25f, 0.f), sx = fmaxf(cx * 0.5f - 0.25f, 0.f);
                     const int iy0 = (int)sy, ix0 = (int)sx;
                     const float ly = sy - iy0, lx = sx - ix0;
                     const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
-                    const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + q * 4;
+                    const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + (q_lo + q) * 4;
                     const f32x4 v00 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
                     const f32x4 v01 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
                     const f32x4 v10 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
@@ -501,17 +521,23 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int coff
     }
 }
 
-template <typename T, int MW, int NW>
-__global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
+// KD x KD conv, stride S, dilation D, padding (KD-1)/2*D, as an LDS-tiled implicit GEMM.
+// The concatenated input channels are processed in chunks of a.CC channels (one chunk for the
+// mobilenetv3 decoder; several for the resnet50 layers whose halo patch would not fit LDS);
+// K index inside a chunk = tap * chunk_channels + channel.
+template <typename T, int MW, int NW, int KD, int S, int D>
+__global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* patch = (T*)smem;
-    constexpr int TH = 4 * MW, PH = TH + 2, PW = 18;
+    typedef ConvGeo<MW, KD, S, D> G;
+    constexpr int TH = G::TH, PH = G::PH, PW = G::PW, KK = KD * KD;
     constexpr int PF = sizeof(T) == 2 ? 8 : 4;              // weight-fragment prefetch depth (K steps)
-    const int CSL = a.Cpad + Tr<T>::kLdsPad;
+    const int CSL = a.CC + Tr<T>::kLdsPad;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int y0 = ty * TH, x0 = tx * 16, n = blockIdx.z;
-    const int H = a.H, W = a.W;
+    const int H = a.H, W = a.W;                             // output size
+    const int gy0 = y0 * S - G::PAD, gx0 = x0 * S - G::PAD; // patch origin in input coordinates
 
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NW;
@@ -529,55 +555,70 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)min(p, a.KS - 1) * 512);
 
-    // ---- stage the (TH+2) x 18 halo patch of the concatenated input ----
-    {
-        int coff = 0;
-        for (int s = 0; s < a.nsrc; ++s) {
-            if (a.src[s].up) stage_source<T, true, PH>(patch, a.src[s], coff, CSL, n, y0, x0, H, W, tid);
-            else stage_source<T, false, PH>(patch, a.src[s], coff, CSL, n, y0, x0, H, W, tid);
-            coff += a.src[s].C;
-        }
-        if (coff < a.Cpad) {                                // zero the pad channels (weights there are 0, keep them finite)
-            for (int pp = tid; pp < PH * PW; pp += 256)
-                for (int cch = coff; cch < a.Cpad; cch += 4) st4f(patch + pp * CSL + cch, f32x4{0, 0, 0, 0});
-        }
-    }
-    __syncthreads();
-
-    // ---- implicit GEMM ----
-    const int NQ8 = a.Cpad >> 3;
-    int tap = 0, c8 = g;
-    while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
-
     f32x4 acc[MW][NW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
-    Frag<T> xf[MW];
-    for (int ks0 = 0; ks0 < a.KS; ks0 += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int ks = ks0 + p;
-            if (ks < a.KS) {
-                const int tp = min(tap, 8);                 // K tail: weights are zero there, keep the read in-bounds
-                const int dy = (tp * 11) >> 5, dx = tp - dy * 3;
-                const T* pb = patch + ((wave + dy) * PW + l15 + dx) * CSL + c8 * 8;
-#pragma unroll
-                for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi) * PW * CSL);
-#pragma unroll
-                for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[mi]);
-                if (ks + PF < a.KS) {
-#pragma unroll
-                    for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)(ks + PF) * 512);
+    int kbase = 0;                                           // global K step at the start of the chunk
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const int c_lo = chunk * a.CC;
+        const int CCc = min(a.CC, a.Cpad - c_lo);
+        const int KSc = a.nchunks > 1 ? ((KK * CCc + 31) / 32 + 7) / 8 * 8 : a.KS;
+        if (chunk > 0) __syncthreads();                      // everyone is done reading the previous patch
+        // ---- stage the halo patch of this channel chunk ----
+        {
+            int coff = 0;
+            for (int s = 0; s < a.nsrc; ++s) {
+                const int C = a.src[s].C;
+                const int lo = max(c_lo, coff), hi = min(c_lo + CCc, coff + C);
+                if (hi > lo) {
+                    const int q_lo = (lo - coff) >> 2, q_cnt = (hi - lo) >> 2, dst_c = lo - c_lo;
+                    if (a.src[s].up)
+                        stage_source<T, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
+                    else
+                        stage_source<T, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
                 }
-                c8 += 4;
-                while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+                coff += C;
+            }
+            const int used = min(max(coff - c_lo, 0), CCc);  // zero the pad channels (weights there are 0, keep them finite)
+            if (used < CCc) {
+                for (int pp = tid; pp < PH * PW; pp += 256)
+                    for (int cch = used; cch < CCc; cch += 4) st4f(patch + pp * CSL + cch, f32x4{0, 0, 0, 0});
             }
         }
+        __syncthreads();
+
+        // ---- implicit GEMM over this chunk ----
+        const int NQ8 = CCc >> 3;
+        int tap = 0, c8 = g;
+        while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+        Frag<T> xf[MW];
+        for (int ks0 = 0; ks0 < KSc; ks0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int ks = ks0 + p;
+                if (ks < KSc) {
+                    const int tp = min(tap, KK - 1);        // K tail: weights are zero there, keep the read in-bounds
+                    const int dy = tp / KD, dx = tp - dy * KD;
+                    const T* pb = patch + ((wave * S + dy * D) * PW + l15 * S + dx * D) * CSL + c8 * 8;
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi * S) * PW * CSL);
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[mi]);
+                    if (kbase + ks + PF < a.KS) {
+#pragma unroll
+                        for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)(kbase + ks + PF) * 512);
+                    }
+                    c8 += 4;
+                    while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+                }
+            }
+        }
+        kbase += KSc;
     }
 
     // ---- epilogue ----
@@ -633,22 +674,26 @@ __global__ __launch_bounds__(256) void conv3x3(ConvArgs a) {
     }
 }
 
-template <typename T, int MW, int NW>
-static void launch_conv3_t(const ConvArgs& a, int N, hipStream_t s) {
+template <typename T, int MW, int NW, int KD, int S, int D>
+static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
-    hipLaunchKernelGGL((conv3x3<T, MW, NW>), grid, dim3(256), conv3_lds_bytes<T>(MW, a.Cpad), s, a);
+    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(256), conv_lds_bytes<T>(MW, KD, S, D, a.CC), s, a);
 }
-template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, hipStream_t s) {
-    if (MW == 4 && NW == 1) launch_conv3_t<T, 4, 1>(a, N, s);
-    else if (MW == 2 && NW == 2) launch_conv3_t<T, 2, 2>(a, N, s);
-    else if (MW == 2 && NW == 1) launch_conv3_t<T, 2, 1>(a, N, s);
-    else if (MW == 1 && NW == 2) launch_conv3_t<T, 1, 2>(a, N, s);
-    else launch_conv3_t<T, 1, 1>(a, N, s);
+// geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
+template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
+    if (geo == 1) { launch_conv_t<T, 1, 2, 3, 2, 1>(a, N, s); return; }
+    if (geo == 2) { launch_conv_t<T, 1, 2, 3, 1, 2>(a, N, s); return; }
+    if (geo == 3) { launch_conv_t<T, 1, 2, 7, 2, 1>(a, N, s); return; }
+    if (MW == 4 && NW == 1) launch_conv_t<T, 4, 1, 3, 1, 1>(a, N, s);
+    else if (MW == 2 && NW == 2) launch_conv_t<T, 2, 2, 3, 1, 1>(a, N, s);
+    else if (MW == 2 && NW == 1) launch_conv_t<T, 2, 1, 3, 1, 1>(a, N, s);
+    else if (MW == 1 && NW == 2) launch_conv_t<T, 1, 2, 3, 1, 1>(a, N, s);
+    else launch_conv_t<T, 1, 1, 3, 1, 1>(a, N, s);
 }
-template void launch_conv3<f16>(const ConvArgs&, int, int, int, hipStream_t);
-template void launch_conv3<float>(const ConvArgs&, int, int, int, hipStream_t);
+template void launch_conv3<f16>(const ConvArgs&, int, int, int, int, hipStream_t);
+template void launch_conv3<float>(const ConvArgs&, int, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Stem: ImageNet normalise + 3x3 stride-2 conv 3->16 + BN + hardswish
@@ -1048,14 +1093,53 @@ template void launch_proj_out<f16>(const ProjOutArgs&, int, bool, hipStream_t);
 template void launch_proj_out<float>(const ProjOutArgs&, int, bool, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int MW, int NW> static void conv3_attr() {
-    (void)hipFuncSetAttribute((const void*)conv3x3<T, MW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+// 3x3 stride-2 pad-1 max pool on NHWC (torchvision ResNet.maxpool, reference resnet.py:25).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s2(MaxPoolArgs a) {
+    const int CG = a.C >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (idx >= a.Ho * a.Wo * CG) return;
+    const int p = idx / CG, cg = idx - p * CG;
+    const int oy = p / a.Wo, ox = p - oy * a.Wo;
+    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.C + cg * 8;
+    f32x4 m0 = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, m1 = m0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+        if (iy < 0 || iy >= a.Hi) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (ix < 0 || ix >= a.Wi) continue;
+            const F8 v = ld8f(xb + ((size_t)iy * a.Wi + ix) * a.C);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { m0[r] = fmaxf(m0[r], v.lo[r]); m1[r] = fmaxf(m1[r], v.hi[r]); }
+        }
+    }
+    F8 o; o.lo = m0; o.hi = m1;
+    st8f((T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * a.C + cg * 8, o);
+}
+template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s) {
+    const int total = a.Ho * a.Wo * (a.C >> 3);
+    hipLaunchKernelGGL((maxpool3s2<T>), dim3((total + 255) / 256, N), dim3(256), 0, s, a);
+}
+template void launch_maxpool<f16>(const MaxPoolArgs&, int, hipStream_t);
+template void launch_maxpool<float>(const MaxPoolArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int MW, int NW, int KD, int S, int D> static void conv_attr() {
+    (void)hipFuncSetAttribute((const void*)conv_kxk<T, MW, NW, KD, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <typename T> static void conv_attr_all() {
+    conv_attr<T, 4, 1, 3, 1, 1>(); conv_attr<T, 2, 2, 3, 1, 1>(); conv_attr<T, 2, 1, 3, 1, 1>();
+    conv_attr<T, 1, 2, 3, 1, 1>(); conv_attr<T, 1, 1, 3, 1, 1>();
+    conv_attr<T, 1, 2, 3, 2, 1>(); conv_attr<T, 1, 2, 3, 1, 2>(); conv_attr<T, 1, 2, 7, 2, 1>();
 }
 void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv3_attr<f16, 4, 1>(); conv3_attr<f16, 2, 2>(); conv3_attr<f16, 2, 1>(); conv3_attr<f16, 1, 2>(); conv3_attr<f16, 1, 1>();
-    conv3_attr<float, 4, 1>(); conv3_attr<float, 2, 2>(); conv3_attr<float, 2, 1>(); conv3_attr<float, 1, 2>(); conv3_attr<float, 1, 1>();
+    conv_attr_all<f16>(); conv_attr_all<float>();
 }

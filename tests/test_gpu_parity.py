@@ -105,15 +105,34 @@ def test_fp16fast_is_fp16_accurate(gc):
     assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
 
 
+# ------------------------------------------------------------------ resnet50 variant (BASELINE configs[3])
+def test_resnet50_fp32_all_taps(gc):
+    """7x7 s2 stem, max-pool, strided / dilated / channel-chunked 3x3 bottleneck convs, strided 1x1."""
+    w = gc.run("fp32", H=122, W=218, ds=0.25, T=2, variant="resnet50", verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+
+
+def test_resnet50_fp16_hd_frame(gc):
+    w = gc.run("fp16", H=1080, W=1920, ds=0.25, T=2, variant="resnet50", verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+
+
+def test_resnet50_fp16fast(gc):
+    w = gc.run("fp16fast", H=122, W=218, ds=0.25, T=2, variant="resnet50", verbose=False)
+    assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
+
+
 # ------------------------------------------------------------------ golden fixture (no oracle involved)
-@pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast"])
+@pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast", "resnet50_ds025"])
 def test_against_committed_fixture(name):
     from robustvideomatting_amd import MattingNetwork, synthetic
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_%s.npz" % name))
     H, W, T, seed = (int(x) for x in g["meta"])
     ds, refiner = float(g["ds"]), str(g["refiner"])
-    m = MattingNetwork("mobilenetv3", refiner).eval()
-    m.load_state_dict(synthetic.make_params("mobilenetv3", refiner, seed=seed))
+    variant = name.split("_")[0]
+    m = MattingNetwork(variant, refiner).eval()
+    m.load_state_dict(synthetic.make_params(variant, refiner, seed=seed))
     m = m.cuda()
     clip = synthetic.make_clip(T, H, W, seed=seed).cuda()
     with torch.no_grad():
