@@ -70,6 +70,7 @@ struct ConvArgs {
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
     void* hout;                             // GRU new state [N][H][W][hC]
     int state16;                            // hprev / hout are fp16 although the kernel computes in fp32
+    int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
 // ---- stem ---------------------------------------------------------------------------------
@@ -112,7 +113,7 @@ template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
-template <typename T> size_t conv_lds_bytes(int MW, int KD, int S, int D, int CC);
+template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC);
 void dw_block_shape(int C, int* cgb, int* pyb);
 size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
 template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);

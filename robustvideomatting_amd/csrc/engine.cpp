@@ -8,6 +8,7 @@
 #include "../../include/rvm_mi355x.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -276,6 +277,7 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
                 size_t& w_off, size_t& b_off, int& KS, int& NT) {
     KS = (int)kmap.size() / 32;
     NT = (int)out_map.size() / 16;
+    const bool planar = c->dtype != RVM_DTYPE_F16;
     std::vector<float> fr((size_t)NT * KS * 512, 0.f), bias((size_t)NT * 16, 0.f);
     for (int nt = 0; nt < NT; ++nt)
         for (int ks = 0; ks < KS; ++ks)
@@ -287,7 +289,9 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
                     if (e.tap < 0) continue;
                     const int i = in_map[e.pc];
                     if (i < 0) continue;
-                    fr[(((size_t)nt * KS + ks) * 64 + lane) * 8 + j] = W[((size_t)o * Cin + i) * KK + e.tap] * af.scale[o];
+                    // fp16: lane-major [64][8]; fp32: two planes [2][64][4] (Frag<float>::loadw)
+                    const size_t fo = planar ? (size_t)(j >> 2) * 256 + lane * 4 + (j & 3) : (size_t)lane * 8 + j;
+                    fr[((size_t)nt * KS + ks) * 512 + fo] = W[((size_t)o * Cin + i) * KK + e.tap] * af.scale[o];
                 }
             }
     for (size_t po = 0; po < out_map.size(); ++po)
@@ -332,7 +336,7 @@ bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, in
 // NHWC4 image sources, get zero weights).
 size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     const int KD = geo == 3 ? 7 : 3, S = (geo == 1 || geo == 3) ? 2 : 1, D = geo == 2 ? 2 : 1;
-    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, KD, S, D, CC) : conv_lds_bytes<float>(MW, KD, S, D, CC);
+    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC);
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
                 const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0) {
@@ -605,24 +609,32 @@ int build_plan(rvm_ctx* c) {
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
         a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
         a.CC = L.CC; a.nchunks = L.nchunks;
+        { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) : 0; }
         // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
         int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
         int MW = 1;
         const int geo = L.geo;
         if (geo == 0 && L.nchunks == 1) {
-            const int mws[3] = {4, 2, 1};
-            for (int k = 0; k < 3; ++k) {
-                int m = mws[k];
-                if (NW == 2 && m == 4) continue;
-                if (conv_lds_bytes<T>(m, 3, 1, 1, L.CC) > 150 * 1024) continue;
-                int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, NW) * B;
-                if (blocks >= 256 || m == 1) { MW = m; break; }
+            // pick the (MW, NW) tile that minimises rounds-of-blocks x work-per-block; a round is
+            // 256 CUs x the blocks whose LDS fits a CU together (ties: the larger tile, less halo)
+            const int cand[5][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+            double best = 1e30;
+            for (int k = 0; k < 5; ++k) {
+                const int m = cand[k][0], nw = cand[k][1];
+                if (epi == EPI_GRU_IH && nw != 2) continue;
+                const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC);
+                if (lds > 150 * 1024) continue;
+                const int occ = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+                const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
+                const double cost = (double)cdiv(blocks, 256 * occ) * m * nw;
+                if (cost < best - 1e-9) { best = cost; MW = m; NW = nw; }
             }
+            if (best > 1e29) return fail("conv: input patch does not fit LDS");
         } else {
             NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
             if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
         }
-        if (conv_lds(c, MW, geo, L.CC) > 160 * 1024) return fail("conv: input patch does not fit LDS");
+        if (conv_lds_bytes<T>(MW, NW, L.KD, (geo == 1 || geo == 3) ? 2 : 1, geo == 2 ? 2 : 1, L.CC) > 160 * 1024) return fail("conv: input patch does not fit LDS");
         const double KK = (double)L.KD * L.KD;
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
             ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es,

@@ -48,12 +48,19 @@ template <typename T> struct Frag;
 template <> struct Frag<f16> {
     f16x8 v;
     __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
+    // packed weight fragment (512 elements): lane l owns elements [8l, 8l+8)
+    __device__ __forceinline__ void loadw(const f16* frag, int lane) { v = *(const f16x8*)(frag + lane * 8); }
     __device__ __forceinline__ void zero() { v = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
     __device__ __forceinline__ void scale(const f16* s) { v = v * *(const f16x8*)s; }
 };
 template <> struct Frag<float> {
     f32x4 lo, hi;
     __device__ __forceinline__ void load(const float* p) { lo = *(const f32x4*)p; hi = *(const f32x4*)(p + 4); }
+    // packed weight fragment (512 elements) is stored as two planes of 64 x 4 floats so that both the
+    // global load and the LDS read are 16 contiguous bytes per lane (no 32-byte lane stride)
+    __device__ __forceinline__ void loadw(const float* frag, int lane) {
+        lo = *(const f32x4*)(frag + lane * 4); hi = *(const f32x4*)(frag + 256 + lane * 4);
+    }
     __device__ __forceinline__ void zero() { lo = f32x4{0, 0, 0, 0}; hi = lo; }
     __device__ __forceinline__ void scale(const float* s) { lo = lo * *(const f32x4*)s; hi = hi * *(const f32x4*)(s + 4); }
 };
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) {
         nv[ni] = (nt0 + ni) < a.NT;
-        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
+        wp[ni] = (const T*)a.w + (size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 512;
     }
     const T* sc = a.in_scale ? (const T*)a.in_scale + (size_t)n * a.Cin : nullptr;
 
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     auto load_step = [&](int ks, Frag<T>* wo, Frag<T>* xo) {
         const int c = ks * 32 + g * 8;
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) wo[ni].load(wp[ni] + (size_t)ks * 512);
+        for (int ni = 0; ni < NW; ++ni) wo[ni].loadw(wp[ni] + (size_t)ks * 512, lane);
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             if (pv[mi] && c < a.Cin) {
@@ -461,28 +468,37 @@ template <int MW, int KD, int S, int D> struct ConvGeo {
     static constexpr int PW = 15 * S + (KD - 1) * D + 1;
     static constexpr int PAD = (KD - 1) / 2 * D;
 };
-template <typename T> size_t conv_lds_bytes(int MW, int KD, int S, int D, int CC) {
+// LDS of one conv_kxk block: halo patch + double-buffered weight stages (SK K-steps x NW n-tiles)
+template <typename T> constexpr int conv_sk() { return sizeof(T) == 2 ? 4 : 2; }
+template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC) {
     const int PH = (4 * MW - 1) * S + (KD - 1) * D + 1, PW = 15 * S + (KD - 1) * D + 1;
-    return (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T);
+    return (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T) + (size_t)2 * conv_sk<T>() * NW * 512 * sizeof(T);
 }
-template size_t conv_lds_bytes<f16>(int, int, int, int, int);
-template size_t conv_lds_bytes<float>(int, int, int, int, int);
+template size_t conv_lds_bytes<f16>(int, int, int, int, int, int);
+template size_t conv_lds_bytes<float>(int, int, int, int, int, int);
 
 // Stage channel quads [q_lo, q_lo+q_cnt) of one source of the concatenated conv input into the
 // LDS halo patch (origin gy0,gx0 in source-resolution coordinates).  The (pixel, quad) items are
 // walked as one flat index, several per thread per round, with a branch-free body (clamped
 // address + select): 8 (direct) or 16 (bilinear) independent loads are in flight per thread,
 // which is what hides the L2 / Infinity-Cache latency of these small tensors.
-template <typename T, bool UP, int PH, int PW>
+template <typename T, bool UP, bool HF, int PH, int PW>
 __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo, int q_cnt, int dst_c, int CSL, int n,
                                              int gy0, int gx0, int H, int W, int tid) {
     constexpr int UN = UP ? 4 : 8;
     const int QN = q_cnt;
     const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16 .. see below
     const int total = PH * PW * QN;
-    const bool hf = sizeof(T) == 2 || S.f16;
+    constexpr bool hf = HF;                                  // compile-time: keeps the loads of a round branch-free
     const bool live = S.p != nullptr;
-    const void* base = live ? S.p : (const void*)patch;      // never dereferenced when !live
+    if (!live) {                                             // no state yet (first frame): zeros
+        for (int it = tid; it < total; it += 256) {
+            const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
+            st4f(patch + pp * CSL + dst_c + q * 4, f32x4{0, 0, 0, 0});
+        }
+        return;
+    }
+    const void* base = S.p;
     for (int it0 = tid; it0 < total; it0 += 256 * UN) {
         f32x4 v[UN];
         int dst[UN];
@@ -495,8 +511,7 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
             const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
             dst[u] = (it0 + u * 256 < total) ? pp * CSL + dst_c + q * 4 : -1;
-            v[u] = f32x4{0, 0, 0, 0};
-            if (live) {
+            {
                 if (!UP) {
                     v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + (q_lo + q) * 4, hf);
                 } else {
@@ -531,8 +546,13 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
     T* patch = (T*)smem;
     typedef ConvGeo<MW, KD, S, D> G;
     constexpr int TH = G::TH, PH = G::PH, PW = G::PW, KK = KD * KD;
-    constexpr int PF = sizeof(T) == 2 ? 8 : 4;              // weight-fragment prefetch depth (K steps)
+    constexpr int SK = conv_sk<T>();                        // K steps per weight stage
+    constexpr int WSTAGE = SK * NW * 512;                   // elements per stage
+    constexpr int EPP = 16 / sizeof(T);                     // elements per 16-byte piece
+    constexpr int NP = WSTAGE / EPP / 256;                  // pieces per thread per stage
+    constexpr int PPS = 512 / EPP;                          // pieces per (step, tile) fragment
     const int CSL = a.CC + Tr<T>::kLdsPad;
+    T* wbuf = patch + (size_t)PH * PW * CSL;                // [2][NW][SK][512]
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int y0 = ty * TH, x0 = tx * 16, n = blockIdx.z;
@@ -541,19 +561,31 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
 
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NW;
-    const T* wp[NW];
     bool nv[NW];
 #pragma unroll
-    for (int ni = 0; ni < NW; ++ni) {
-        nv[ni] = (nt0 + ni) < a.NT;
-        wp[ni] = (const T*)a.w + ((size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 64 + lane) * 8;
-    }
-    // start streaming the first weight fragments before the patch is staged
-    Frag<T> wf[PF][NW];
+    for (int ni = 0; ni < NW; ++ni) nv[ni] = (nt0 + ni) < a.NT;
+
+    // Weight stages: the block's NW n-tiles x SK K-steps are fetched ONCE per block (16-byte pieces,
+    // all 256 threads), parked in registers while the previous stage is consumed, then written to
+    // the other LDS buffer.  Every wave reads its fragments from LDS, so the L2 sees each weight
+    // line once per block instead of once per wave.
+    f32x4 wr[NP];
+    auto wload = [&](int gs) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j;
+            const int ni = i / (SK * PPS), rem = i - ni * (SK * PPS);
+            const int sidx = rem / PPS, r = rem - sidx * PPS;
+            const int step = min(gs + sidx, a.KS - 1);
+            const int tile = min(nt0 + ni, a.NT - 1);
+            wr[j] = *(const f32x4*)((const char*)a.w + (((size_t)tile * a.KS + step) * 512) * sizeof(T) + (size_t)r * 16);
+        }
+    };
+    auto wstore = [&](int buf) {
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)min(p, a.KS - 1) * 512);
+        for (int j = 0; j < NP; ++j) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + 256 * j) * 16) = wr[j];
+    };
+    wload(0);                                               // in flight while the patch is staged
 
     f32x4 acc[MW][NW];
 #pragma unroll
@@ -561,24 +593,28 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
-    int kbase = 0;                                           // global K step at the start of the chunk
+    int gs = 0, buf = 0;                                     // global K step at the start of the stage
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const int c_lo = chunk * a.CC;
         const int CCc = min(a.CC, a.Cpad - c_lo);
         const int KSc = a.nchunks > 1 ? ((KK * CCc + 31) / 32 + 7) / 8 * 8 : a.KS;
-        if (chunk > 0) __syncthreads();                      // everyone is done reading the previous patch
-        // ---- stage the halo patch of this channel chunk ----
+        // ---- stage the halo patch of this channel chunk (the stage loop below ends with a barrier,
+        //      so nobody still reads the previous chunk's patch)
         {
             int coff = 0;
             for (int s = 0; s < a.nsrc; ++s) {
                 const int C = a.src[s].C;
                 const int lo = max(c_lo, coff), hi = min(c_lo + CCc, coff + C);
-                if (hi > lo) {
+                if (hi > lo && !(a.dbg & 1)) {
                     const int q_lo = (lo - coff) >> 2, q_cnt = (hi - lo) >> 2, dst_c = lo - c_lo;
-                    if (a.src[s].up)
-                        stage_source<T, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
-                    else
-                        stage_source<T, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
+                    const bool hf = sizeof(T) == 2 || a.src[s].f16;
+                    if (a.src[s].up) {
+                        if (hf) stage_source<T, true, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
+                        else stage_source<T, true, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
+                    } else {
+                        if (hf) stage_source<T, false, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
+                        else stage_source<T, false, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
+                    }
                 }
                 coff += C;
             }
@@ -588,37 +624,41 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
                     for (int cch = used; cch < CCc; cch += 4) st4f(patch + pp * CSL + cch, f32x4{0, 0, 0, 0});
             }
         }
+        if (chunk == 0) wstore(0);
         __syncthreads();
 
-        // ---- implicit GEMM over this chunk ----
+        // ---- implicit GEMM over this chunk, SK steps per weight stage ----
         const int NQ8 = CCc >> 3;
         int tap = 0, c8 = g;
         while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
-        Frag<T> xf[MW];
-        for (int ks0 = 0; ks0 < KSc; ks0 += PF) {
+        for (int ks0 = 0; ks0 < ((a.dbg & 2) ? 0 : KSc); ks0 += SK) {
+            const bool more = gs + SK < a.KS;
+            if (more) wload(gs + SK);
+            const T* wst = wbuf + (size_t)buf * WSTAGE;
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const int ks = ks0 + p;
-                if (ks < KSc) {
+            for (int p = 0; p < SK; ++p) {
+                if (ks0 + p < KSc && !(a.dbg & 4)) {
                     const int tp = min(tap, KK - 1);        // K tail: weights are zero there, keep the read in-bounds
                     const int dy = tp / KD, dx = tp - dy * KD;
                     const T* pb = patch + ((wave * S + dy * D) * PW + l15 * S + dx * D) * CSL + c8 * 8;
+                    Frag<T> xf[MW], wf[NW];
 #pragma unroll
                     for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi * S) * PW * CSL);
 #pragma unroll
+                    for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wst + (ni * SK + p) * 512, lane);
+#pragma unroll
                     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[mi]);
-                    if (kbase + ks + PF < a.KS) {
-#pragma unroll
-                        for (int ni = 0; ni < NW; ++ni) wf[p][ni].load(wp[ni] + (size_t)(kbase + ks + PF) * 512);
-                    }
+                        for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
                     c8 += 4;
                     while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
                 }
             }
+            if (more) wstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            gs += SK;
         }
-        kbase += KSc;
     }
 
     // ---- epilogue ----
@@ -679,7 +719,7 @@ static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
-    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(256), conv_lds_bytes<T>(MW, KD, S, D, a.CC), s, a);
+    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(256), conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC), s, a);
 }
 // geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
