@@ -13,6 +13,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -171,6 +172,7 @@ struct FrameIO {
 
 struct rvm_ctx {
     int variant, refiner, dtype, device;
+    bool split = false;             // F16IO: GEMM operands as (hi, lo) fp16 pairs on the f16 MFMA (common.hpp f32s)
     std::vector<ParamSpec> specs;
     std::map<std::string, std::vector<float>> params;
     bool finalized = false;
@@ -277,7 +279,7 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
                 size_t& w_off, size_t& b_off, int& KS, int& NT) {
     KS = (int)kmap.size() / 32;
     NT = (int)out_map.size() / 16;
-    const bool planar = c->dtype != RVM_DTYPE_F16;
+    const bool planar = c->dtype != RVM_DTYPE_F16 && !c->split;
     std::vector<float> fr((size_t)NT * KS * 512, 0.f), bias((size_t)NT * 16, 0.f);
     for (int nt = 0; nt < NT; ++nt)
         for (int ks = 0; ks < KS; ++ks)
@@ -297,7 +299,19 @@ void pack_frags(rvm_ctx* c, const std::vector<float>& W, int Cin, int KK, const 
     for (size_t po = 0; po < out_map.size(); ++po)
         if (out_map[po] >= 0) bias[po] = af.shift[out_map[po]];
     w_off = c->blob_alloc(fr.size() * c->esize());
-    put_elems(c, w_off, fr);
+    if (c->split) {
+        // per fragment: 512 hi halves (lane-major [64][8]) then 512 lo halves, lo = fp16(w - hi)
+        f16* d = (f16*)(c->blob.data() + w_off);
+        for (size_t fi = 0; fi < fr.size() / 512; ++fi)
+            for (int e = 0; e < 512; ++e) {
+                const float w = fr[fi * 512 + e];
+                const f16 hi = (f16)w;
+                d[fi * 1024 + e] = hi;
+                d[fi * 1024 + 512 + e] = (f16)(w - (float)hi);
+            }
+    } else {
+        put_elems(c, w_off, fr);
+    }
     b_off = put_floats(c, bias);
 }
 // K order of conv_kxk: channel chunks of CC; inside a chunk k = tap * chunk_channels + channel; a
@@ -336,7 +350,7 @@ bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, in
 // NHWC4 image sources, get zero weights).
 size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     const int KD = geo == 3 ? 7 : 3, S = (geo == 1 || geo == 3) ? 2 : 1, D = geo == 2 ? 2 : 1;
-    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC);
+    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC);   // f32s == float
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
                 const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0) {
@@ -554,12 +568,23 @@ int pick_pw_cfg(int MT, int NT, int N) {
     return best;
 }
 
+// GEMM launchers: the fp32-storage plan runs them on the split type when ctx->split is set
+template <typename T> void launch_pw_m(const PwArgs& a, int N, int cfg, hipStream_t s, bool split) {
+    if constexpr (std::is_same<T, float>::value) { if (split) { launch_pw<f32s>(a, N, cfg, s); return; } }
+    launch_pw<T>(a, N, cfg, s);
+}
+template <typename T> void launch_conv3_m(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s, bool split) {
+    if constexpr (std::is_same<T, float>::value) { if (split) { launch_conv3<f32s>(a, N, MW, NW, geo, s); return; } }
+    launch_conv3<T>(a, N, MW, NW, geo, s);
+}
+
 template <typename T>
 int build_plan(rvm_ctx* c) {
     c->launches.clear();
     c->taps.clear();
     c->arena_used = 0;
     const int B = c->B;
+    const bool split = c->split;
     const size_t es = sizeof(T);
     const int io16 = c->dtype == RVM_DTYPE_F16IO ? 1 : 0;   // fp16 tensors at the boundary, fp32 inside
     const size_t ies = c->dtype == RVM_DTYPE_F32 ? 4 : 2;   // element size of src / fgr / pha
@@ -599,7 +624,7 @@ int build_plan(rvm_ctx* c) {
         const int cfg = pick_pw_cfg(a.MT, a.NT, B);
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
-            [=](hipStream_t st, const FrameIO&) { launch_pw<T>(a, B, cfg, st); });
+            [=](hipStream_t st, const FrameIO&) { launch_pw_m<T>(a, B, cfg, st, split); });
     };
 
     // KxK conv launcher: (Ho, Wo) output, (Hi, Wi) input of the direct sources
@@ -638,7 +663,7 @@ int build_plan(rvm_ctx* c) {
         const double KK = (double)L.KD * L.KD;
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
             ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es,
-            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3<T>(b, B, MW, NW, geo, st); });
+            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3_m<T>(b, B, MW, NW, geo, st, split); });
         return 0;
     };
 
@@ -957,6 +982,10 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     if (device < 64 && !inited[device]) { kernels_init(); inited[device] = true; }
     rvm_ctx* c = new rvm_ctx();
     c->variant = variant; c->refiner = refiner; c->dtype = dtype; c->device = device;
+    if (dtype == RVM_DTYPE_F16IO) {
+        const char* e = getenv("RVM_F16IO_MFMA");               // "f32": exact fp32 MFMA instead of the f16 split
+        c->split = !(e && std::string(e) == "f32");
+    }
     c->specs = param_specs(variant, refiner);
     *out = c;
     return 0;

@@ -35,6 +35,25 @@ __device__ __forceinline__ void st8f(f16* p, F8 v) {
 }
 __device__ __forceinline__ void st8f(float* p, F8 v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
 
+// split type: plain fp32 in global memory
+__device__ __forceinline__ f32x4 ld4f(const f32s* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ void st4f(f32s* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
+    hi = __builtin_convertvector(v, f16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+}
+// LDS halo-patch stores: 4 channels c..c+3 (c % 4 == 0) of the pixel whose row starts at `row`.
+// f16 / float: channel-major row.  split: per 8-channel group [8 x hi f16][8 x lo f16] (32 B).
+__device__ __forceinline__ void stp4(f16* row, int c, f32x4 v) { st4f(row + c, v); }
+__device__ __forceinline__ void stp4(float* row, int c, f32x4 v) { st4f(row + c, v); }
+__device__ __forceinline__ void stp4(f32s* row, int c, f32x4 v) {
+    f16x4 hi, lo;
+    split4(v, hi, lo);
+    f16* g = (f16*)(row + (c & ~7)) + (c & 7);
+    *(f16x4*)g = hi;
+    *(f16x4*)(g + 8) = lo;
+}
+
 // element-typed access through a runtime flag (fp16 tensors at the API boundary of the mixed mode)
 __device__ __forceinline__ f32x4 ld4x(const void* p, size_t i, bool half) {
     return half ? ld4f((const f16*)p + i) : ld4f((const float*)p + i);
@@ -48,6 +67,7 @@ template <typename T> struct Frag;
 template <> struct Frag<f16> {
     f16x8 v;
     __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
+    __device__ __forceinline__ void load_lds(const f16* p) { v = *(const f16x8*)p; }
     // packed weight fragment (512 elements): lane l owns elements [8l, 8l+8)
     __device__ __forceinline__ void loadw(const f16* frag, int lane) { v = *(const f16x8*)(frag + lane * 8); }
     __device__ __forceinline__ void zero() { v = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -56,6 +76,7 @@ template <> struct Frag<f16> {
 template <> struct Frag<float> {
     f32x4 lo, hi;
     __device__ __forceinline__ void load(const float* p) { lo = *(const f32x4*)p; hi = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void load_lds(const float* p) { load(p); }
     // packed weight fragment (512 elements) is stored as two planes of 64 x 4 floats so that both the
     // global load and the LDS read are 16 contiguous bytes per lane (no 32-byte lane stride)
     __device__ __forceinline__ void loadw(const float* frag, int lane) {
@@ -65,7 +86,36 @@ template <> struct Frag<float> {
     __device__ __forceinline__ void scale(const float* s) { lo = lo * *(const f32x4*)s; hi = hi * *(const f32x4*)(s + 4); }
 };
 
+template <> struct Frag<f32s> {
+    f16x8 hi, lo;
+    // from global memory: 8 fp32 values, split in registers
+    __device__ __forceinline__ void load(const f32s* p) { set(*(const f32x4*)p, *(const f32x4*)((const float*)p + 4)); }
+    __device__ __forceinline__ void set(f32x4 a, f32x4 b) {
+        f16x4 h0, l0, h1, l1;
+        split4(a, h0, l0); split4(b, h1, l1);
+        hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // from the LDS halo patch: already split (stp4)
+    __device__ __forceinline__ void load_lds(const f32s* p) { hi = *(const f16x8*)p; lo = *(const f16x8*)((const f16*)p + 8); }
+    // packed weight fragment (512 x 4 bytes): [64 lanes][8] hi halves, then [64][8] lo halves
+    __device__ __forceinline__ void loadw(const f32s* frag, int lane) {
+        hi = *(const f16x8*)((const f16*)frag + lane * 8); lo = *(const f16x8*)((const f16*)frag + 512 + lane * 8);
+    }
+    __device__ __forceinline__ void zero() { hi = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; lo = hi; }
+};
+template <typename T> __device__ __forceinline__ void load_scaled(Frag<T>& f, const T* p, const T* s) { f.load(p); f.scale(s); }
+template <> __device__ __forceinline__ void load_scaled<f32s>(Frag<f32s>& f, const f32s* p, const f32s* s) {
+    const float* pf = (const float*)p; const float* sf = (const float*)s;
+    f.set(*(const f32x4*)pf * *(const f32x4*)sf, *(const f32x4*)(pf + 4) * *(const f32x4*)(sf + 4));
+}
+
 // acc(16 out-channels x 16 pixels) += W(16 x 32) * X(32 x 16)
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<f32s>& w, const Frag<f32s>& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.lo, x.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x.hi, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma(f32x4& acc, const Frag<f16>& w, const Frag<f16>& x) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.v, x.v, acc, 0, 0, 0);
 }
@@ -142,8 +192,8 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             if (pv[mi] && c < a.Cin) {
-                xo[mi].load(xp[mi] + ks * 32);
-                if (sc) xo[mi].scale(sc + c);
+                if (sc) load_scaled<T>(xo[mi], xp[mi] + ks * 32, sc + c);
+                else xo[mi].load(xp[mi] + ks * 32);
             } else {
                 xo[mi].zero();
             }
@@ -216,6 +266,7 @@ template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_
 }
 template void launch_pw<f16>(const PwArgs&, int, int, hipStream_t);
 template void launch_pw<float>(const PwArgs&, int, int, hipStream_t);
+template void launch_pw<f32s>(const PwArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Depthwise k x k conv (+folded BN, activation, optional squeeze-excite partial sums).
@@ -476,6 +527,7 @@ template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D
 }
 template size_t conv_lds_bytes<f16>(int, int, int, int, int, int);
 template size_t conv_lds_bytes<float>(int, int, int, int, int, int);
+template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int);
 
 // Stage channel quads [q_lo, q_lo+q_cnt) of one source of the concatenated conv input into the
 // LDS halo patch (origin gy0,gx0 in source-resolution coordinates).  The (pixel, quad) items are
@@ -494,14 +546,14 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
     if (!live) {                                             // no state yet (first frame): zeros
         for (int it = tid; it < total; it += 256) {
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
-            st4f(patch + pp * CSL + dst_c + q * 4, f32x4{0, 0, 0, 0});
+            stp4(patch + pp * CSL, dst_c + q * 4, f32x4{0, 0, 0, 0});
         }
         return;
     }
     const void* base = S.p;
     for (int it0 = tid; it0 < total; it0 += 256 * UN) {
         f32x4 v[UN];
-        int dst[UN];
+        int dst[UN], dch[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int it = min(it0 + u * 256, total - 1);
@@ -510,7 +562,8 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
             const int gy = gy0 + py, gx = gx0 + px;
             const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            dst[u] = (it0 + u * 256 < total) ? pp * CSL + dst_c + q * 4 : -1;
+            dst[u] = (it0 + u * 256 < total) ? pp * CSL : -1;
+            dch[u] = dst_c + q * 4;
             {
                 if (!UP) {
                     v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + (q_lo + q) * 4, hf);
@@ -532,7 +585,7 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
-            if (dst[u] >= 0) st4f(patch + dst[u], v[u]);
+            if (dst[u] >= 0) stp4(patch + dst[u], dch[u], v[u]);
     }
 }
 
@@ -621,7 +674,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
             const int used = min(max(coff - c_lo, 0), CCc);  // zero the pad channels (weights there are 0, keep them finite)
             if (used < CCc) {
                 for (int pp = tid; pp < PH * PW; pp += 256)
-                    for (int cch = used; cch < CCc; cch += 4) st4f(patch + pp * CSL + cch, f32x4{0, 0, 0, 0});
+                    for (int cch = used; cch < CCc; cch += 4) stp4(patch + pp * CSL, cch, f32x4{0, 0, 0, 0});
             }
         }
         if (chunk == 0) wstore(0);
@@ -643,7 +696,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
                     const T* pb = patch + ((wave * S + dy * D) * PW + l15 * S + dx * D) * CSL + c8 * 8;
                     Frag<T> xf[MW], wf[NW];
 #pragma unroll
-                    for (int mi = 0; mi < MW; ++mi) xf[mi].load(pb + (4 * mi * S) * PW * CSL);
+                    for (int mi = 0; mi < MW; ++mi) xf[mi].load_lds(pb + (4 * mi * S) * PW * CSL);
 #pragma unroll
                     for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wst + (ni * SK + p) * 512, lane);
 #pragma unroll
@@ -734,6 +787,7 @@ template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW
 }
 template void launch_conv3<f16>(const ConvArgs&, int, int, int, int, hipStream_t);
 template void launch_conv3<float>(const ConvArgs&, int, int, int, int, hipStream_t);
+template void launch_conv3<f32s>(const ConvArgs&, int, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Stem: ImageNet normalise + 3x3 stride-2 conv 3->16 + BN + hardswish
@@ -1181,5 +1235,5 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv_attr_all<f16>(); conv_attr_all<float>();
+    conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
 }

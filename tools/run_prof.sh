@@ -1,8 +1,15 @@
 # rocprofv3 kernel-trace + stats of the default bench command (run on the GPU box)
+#   MODE=graph|eager  WL=hd|4k  DT=fp16|fp16fast|fp32  TAG=name
 R=$GRAFT_REPO_ROOT
+TAG=${TAG:-hd}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_hd -- python3 $R/bench.py --steps 100 --warmup 10 --mode ${MODE:-graph} --no-cpu-baseline > $R/gpurun_out/prof_hd_stdout.txt 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --mode ${MODE:-graph} --workload ${WL:-hd} --dtype ${DT:-fp16} --no-cpu-baseline --dump-kernels $R/gpurun_out/prof_${TAG}_kernels.json > $R/gpurun_out/prof_${TAG}_stdout.txt 2>&1
 echo exit=$?
-ls -R $R/gpurun_out/prof_hd | head -30
+cd $R
+f=$(ls gpurun_out/prof_$TAG/*/*kernel_trace.csv | head -1)
+python3 tools/trace_table.py $f gpurun_out/prof_${TAG}_kernels.json 50 > gpurun_out/prof_${TAG}_table.txt 2>&1
+cp $(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/prof_${TAG}_kernel_stats.csv
+rm -rf gpurun_out/prof_$TAG
+head -3 gpurun_out/prof_${TAG}_table.txt
