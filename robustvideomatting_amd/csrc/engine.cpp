@@ -553,7 +553,19 @@ int finalize_impl(rvm_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 // schedule
 // ---------------------------------------------------------------------------------------------
-int pick_pw_cfg(int MT, int NT, int N) {
+int pick_pw_cfg(int MT, int NT, int KS, int N) {
+    // Long K on few tiles (the 1/16-scale project / ASPP GEMMs): split K over the block's 4 waves.
+    if (KS >= 8) {
+        const int sm[3] = {2, 1, 1}, sn[3] = {2, 2, 1};      // configs 4, 5, 6
+        for (int k = 0; k < 3; ++k) {
+            const int blocks = cdiv(MT, sm[k]) * cdiv(NT, sn[k]) * N;
+            if (blocks >= 160 || k == 2) {
+                // only when the un-split grid could not fill the chip with 4-wave blocks anyway
+                if (cdiv(MT, 2) * cdiv(NT, 2) * N <= 384) return 4 + k;
+                break;
+            }
+        }
+    }
     // block tile (m-tiles x n-tiles) of pw_gemm configs 0..3, in order of preference
     const int bm[4] = {4, 2, 8, 2}, bn[4] = {4, 2, 1, 4};
     const int pref[4] = {0, 3, 2, 1};
@@ -621,7 +633,7 @@ int build_plan(rvm_ctx* c) {
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
-        const int cfg = pick_pw_cfg(a.MT, a.NT, B);
+        const int cfg = pick_pw_cfg(a.MT, a.NT, a.KS, B);
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
             [=](hipStream_t st, const FrameIO&) { launch_pw_m<T>(a, B, cfg, st, split); });

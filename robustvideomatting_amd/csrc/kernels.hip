@@ -145,14 +145,18 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-
 // model/mobilenetv3.py:39-58, SE rescale (x * scale), residual add, and LR-ASPP aspp1 * aspp2
 // (model/lraspp.py:6-10,18).  BN is folded into w/bias on the host.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MW, int NW, int WM, int WN>
+// KSP = 1: the block's 4 waves own WM x WN different output tiles.  KSP = 4 (small pixel counts, long K):
+// all 4 waves own the SAME MW x NW tile group, each takes every 4th K step, and the partial
+// accumulators are summed through LDS in a fixed order before the epilogue (short dependent chains
+// instead of a 30-step one per wave).
+template <typename T, int MW, int NW, int WM, int WN, int KSP>
 __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm = wave % WM, wn = wave / WM;
-    const int mt0 = (blockIdx.x * WM + wm) * MW;
-    const int nt0 = (blockIdx.y * WN + wn) * NW;
+    const int wm = KSP > 1 ? 0 : wave % WM, wn = KSP > 1 ? 0 : wave / WM;
+    const int mt0 = (blockIdx.x * (KSP > 1 ? 1 : WM) + wm) * MW;
+    const int nt0 = (blockIdx.y * (KSP > 1 ? 1 : WN) + wn) * NW;
     const int n = blockIdx.z;
-    if (mt0 >= a.MT || nt0 >= a.NT) return;
+    if (mt0 >= a.MT || nt0 >= a.NT) return;                  // uniform per block when KSP > 1
     const int l15 = lane & 15, g = lane >> 4;
 
     const T* xp[MW];
@@ -199,20 +203,40 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
             }
         }
     };
+    // this wave's K steps: k0, k0 + KSP, ...
+    const int k0 = KSP > 1 ? wave : 0;
+    const int nst = KSP > 1 ? (a.KS - k0 + KSP - 1) / KSP : a.KS;     // may be 0 for a wave when KS < KSP
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load_step(min(p, a.KS - 1), wf[p], xf[p]);
-    for (int ks0 = 0; ks0 < a.KS; ks0 += PF) {
+    for (int p = 0; p < PF; ++p) load_step(min(k0 + KSP * p, a.KS - 1), wf[p], xf[p]);
+    for (int j0 = 0; j0 < nst; j0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int ks = ks0 + p;
-            if (ks < a.KS) {
+            const int j = j0 + p;
+            if (j < nst) {
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[p][mi]);
-                if (ks + PF < a.KS) load_step(ks + PF, wf[p], xf[p]);
+                if (j + PF < nst) load_step(k0 + KSP * (j + PF), wf[p], xf[p]);
             }
         }
+    }
+
+    if constexpr (KSP > 1) {
+        // fixed-order reduction of the 4 partial accumulators; tile t of the group is finished by wave t % 4
+        __shared__ f32x4 red[KSP][MW * NW][64];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) red[wave][mi * NW + ni][lane] = acc[mi][ni];
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) {
+                const int t = mi * NW + ni;
+                if ((t & 3) == wave) acc[mi][ni] = (red[0][t][lane] + red[1][t][lane]) + (red[2][t][lane] + red[3][t][lane]);
+            }
     }
 
     // epilogue: lane holds channels ch..ch+3 of pixel pix
@@ -225,6 +249,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
         if (a.out_scale && ch < a.Cout) osc = *(const f32x4*)(a.out_scale + (size_t)n * a.oss + ch);
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
+            if (KSP > 1 && ((mi * NW + ni) & 3) != wave) continue;
             const int pix = (mt0 + mi) * 16 + l15;
             f32x4 v = acc[mi][ni] + bias;
             if (!a.act_post) {
@@ -258,10 +283,14 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
     switch (cfg) {
-        case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((pw_gemm<T, 2, 1, 4, 1>), dim3(cdiv(a.MT, 8), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 2, 2>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+        case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2, 1>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_gemm<T, 2, 1, 4, 1, 1>), dim3(cdiv(a.MT, 8), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+        // split-K over the 4 waves: block tile = MW x NW
+        case 4: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 1, 1, 4>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
     }
 }
 template void launch_pw<f16>(const PwArgs&, int, int, hipStream_t);
