@@ -55,9 +55,24 @@ struct DwArgs {
     int C, Hi, Wi, Ho, Wo, stride, dil, pad, act, ppb, nblk;
 };
 
+// ---- fused expand (1x1, MFMA) -> depthwise k x k (LDS) [-> squeeze-excite fc1 partial] -----------
+struct EdArgs {
+    const void* x; int Cin; int xs;         // block input [N][Hi*Wi][xs]
+    const void* w; int KS; int NT;          // expand weight fragments [NT][KS][512]; null: no expand (C == Cin)
+    const float* ebias; int eact;           // [NT*16]
+    const float* dw_w; const float* dw_b;   // [K*K][C], [C] (BN folded)
+    int dact;
+    void* y;                                // depthwise output [N][Ho*Wo][C]
+    const float* fc1_w; int S; float* hpart;// SE: fc1 weights [S][C] (fp32), partial pre-activations [N][nparts][S]; or null
+    int C, Hi, Wi, Ho, Wo, stride, dil, pad;
+    int rb, nband;                          // output rows per band, number of bands
+    int npxs;                               // pixels per channel-quad plane of the LDS tile (>= rows*Wi of any band, multiple of 16)
+};
+
 // ---- small dense layer on pooled vectors (SE fc1/fc2, LR-ASPP gate) ------------------------
 struct GemvArgs {
     const float* xin; int nparts; int part_stride; float xscale;   // x[i] = xscale * sum_p xin[(n*nparts+p)*part_stride+i]
+    const float* xbias; int xact;           // then x[i] = act(x[i] + xbias[i]) when xbias != null (SE fc1 tail)
     const void* w;                          // T [O][I]
     const float* bias;                      // [O] or null
     void* y; int y_is_T;                    // [N][O] float or T
@@ -125,4 +140,6 @@ template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D
 void dw_block_shape(int C, int* cgb, int* pyb);
 size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
 template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);
+template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s);
+size_t ed_lds_bytes(int K, int KS, int npxs, int es);
 void kernels_init();   // one-time function attributes (dynamic LDS limits)

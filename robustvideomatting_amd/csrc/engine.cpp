@@ -155,7 +155,7 @@ std::vector<ParamSpec> param_specs(int variant, int refiner) {
 // ---------------------------------------------------------------------------------------------
 struct PwLayer { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, KS = 0, NT = 0, act = 0; };
 struct DwLayer { size_t w = 0, bias = 0; int C = 0, K = 3, stride = 1, dil = 1, pad = 1, act = 0; };
-struct SeLayer { size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };
+struct SeLayer { size_t w1f = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };   // w1f: fc1 weights [S][C] fp32
 struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0, Cin = 0; int KD = 3, geo = 0, CC = 0, nchunks = 1; };
 struct ResBlock { PwLayer c1, c3, ds; Conv3Layer c2; bool has_ds = false; int stride = 1, planes = 0, inpl = 0; };
 struct GruLayer { Conv3Layer ih, hh; int C = 0; };
@@ -444,7 +444,7 @@ int finalize_impl(rvm_ctx* c) {
                 const int S = se_squeeze(r.exp);
                 std::string q = p + std::to_string(j);
                 b.se.C = r.exp; b.se.S = S;
-                b.se.w1 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w1, *c->P(q + ".fc1.weight"));
+                b.se.w1f = put_floats(c, *c->P(q + ".fc1.weight"));
                 b.se.b1 = put_floats(c, *c->P(q + ".fc1.bias"));
                 b.se.w2 = c->blob_alloc((size_t)S * r.exp * c->esize()); put_elems(c, b.se.w2, *c->P(q + ".fc2.weight"));
                 b.se.b2 = put_floats(c, *c->P(q + ".fc2.bias"));
@@ -703,66 +703,58 @@ int build_plan(rvm_ctx* c) {
             const int olvl = b.dw.stride == 2 ? lvl + 1 : lvl;
             const int Ho = lh[olvl], Wo = lw[olvl];
             const int exp = b.row.exp;
-            const T* ex = cur;
-            if (b.has_expand) {
-                T* e = abuf((size_t)B * Hi * Wi * exp);
-                pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
-                ex = e;
-            }
-            T* dwo = abuf((size_t)B * Ho * Wo * exp);
-            const int npix = Ho * Wo;
-            // small pyramid levels: LDS-tiled kernel (8 channels x a band of output rows per block);
-            // large ones: direct kernel (channel groups x pixel lanes).
             const int K = b.dw.K;
-            bool use_lds = Wi <= 128;
-            int band = Ho, nblk = 1, max_rows = 0;
-            if (use_lds) {
-                // shrink the band until the chip has >= ~96 blocks, keep at least 4 output rows
-                while (band > 4 && (exp / 8) * cdiv(Ho, band) * B < 96) band = cdiv(band, 2);
-                auto rows_for = [&](int bd) { return std::min(Hi, (bd - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
-                while (band > 1 && dw_lds_bytes(K, rows_for(band), Wi, (int)es) > 64 * 1024) band = cdiv(band, 2);
-                max_rows = rows_for(band);
-                nblk = cdiv(Ho, band);
-                if (dw_lds_bytes(K, max_rows, Wi, (int)es) > 150 * 1024) use_lds = false;
-            }
-            int ppb = band;
-            if (!use_lds) {
-                int CGB, PYB;
-                dw_block_shape(exp, &CGB, &PYB);
-                // pixel chunks: ~2 pixels per thread; SE layers cap the number of partial-sum rows at 64
-                nblk = std::max(1, cdiv(npix, PYB * 2));
-                if (b.has_se) nblk = std::min(nblk, 64);
-                ppb = cdiv(npix, nblk);
-                nblk = cdiv(npix, ppb);
-            }
-            float* partial = b.has_se ? fbuf((size_t)B * nblk * exp) : nullptr;
-            {
-                DwArgs a; a.x = ex; a.y = dwo; a.w = (const float*)(wb + b.dw.w); a.bias = (const float*)(wb + b.dw.bias);
-                a.pool = partial; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil;
-                a.pad = b.dw.pad; a.act = b.dw.act; a.ppb = ppb; a.nblk = nblk;
-                add("mb" + std::to_string(i + 1) + ".dw" + std::to_string(K) + "x" + std::to_string(K),
-                    2.0 * B * npix * exp * K * K, (double)B * (Hi * Wi + npix) * exp * es,
-                    [=](hipStream_t st, const FrameIO&) {
-                        if (use_lds) launch_dw_lds<T>(a, B, K, max_rows, st);
-                        else launch_dw<T>(a, B, K, st);
-                    });
-            }
+            const int npix = Ho * Wo;
+            T* dwo = abuf((size_t)B * npix * exp);
             const T* scale = nullptr;
-            if (b.has_se) {
-                float* hidden = fbuf((size_t)B * b.se.S);
-                T* sc = abuf((size_t)B * exp);
-                GemvArgs g1; memset(&g1, 0, sizeof g1);
-                g1.xin = partial; g1.nparts = nblk; g1.part_stride = exp; g1.xscale = 1.f / (float)npix;
-                g1.w = wb + b.se.w1; g1.bias = (const float*)(wb + b.se.b1); g1.y = hidden; g1.y_is_T = 0;
-                g1.I = exp; g1.O = b.se.S; g1.act = ACT_RELU; g1.opw = 2;
-                GemvArgs g2; memset(&g2, 0, sizeof g2);
-                g2.xin = hidden; g2.nparts = 1; g2.part_stride = b.se.S; g2.xscale = 1.f;
-                g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
-                g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
-                const std::string sn = "mb" + std::to_string(i + 1) + ".se_fc";
-                add(sn + "1", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g1, B, st); });
-                add(sn + "2", 2.0 * B * exp * b.se.S, (double)exp * b.se.S * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
-                scale = sc;
+            // ---- expand -> depthwise (-> SE fc1 partials) in one launch: 16 channels x a band of rows per block
+            {
+                const int nslice = cdiv(exp, 16);
+                auto rows_for = [&](int rb) { return std::min(Hi, (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
+                const int KS = b.has_expand ? b.expand.KS : 0;
+                auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(rows_for(rb) * Wi, 16), (int)es); };
+                int rb = Ho;
+                // split into bands while the tile does not fit ~72 KB, or while the grid is small and the
+                // halo rows recomputed by the split stay below 60 % of the image
+                while (rb > 1) {
+                    const int nrb = cdiv(rb, 2);
+                    const bool too_big = lds_for(rb) > 72 * 1024;
+                    const bool few = nslice * cdiv(Ho, rb) * B < 128;
+                    const bool cheap = (double)rows_for(nrb) * cdiv(Ho, nrb) <= 1.6 * Hi;
+                    if (too_big || (few && cheap)) rb = nrb; else break;
+                }
+                EdArgs a; memset(&a, 0, sizeof a);
+                a.x = cur; a.Cin = curC; a.xs = curC;
+                if (b.has_expand) { a.w = wb + b.expand.w; a.KS = b.expand.KS; a.NT = b.expand.NT; a.ebias = (const float*)(wb + b.expand.bias); a.eact = b.expand.act; }
+                a.dw_w = (const float*)(wb + b.dw.w); a.dw_b = (const float*)(wb + b.dw.bias); a.dact = b.dw.act;
+                a.y = dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
+                a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(rows_for(rb) * Wi, 16);
+                if (a.KS > 5 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024) return fail("mbconv_ed: unsupported block shape");
+                const int nparts = nslice * a.nband;
+                float* hpart = nullptr;
+                if (b.has_se) {
+                    hpart = fbuf((size_t)B * nparts * b.se.S);
+                    a.fc1_w = (const float*)(wb + b.se.w1f); a.S = b.se.S; a.hpart = hpart;
+                }
+                const double eflops = b.has_expand ? 2.0 * B * Hi * Wi * curC * exp : 0.0;
+                add("mb" + std::to_string(i + 1) + ".expand_dw" + std::to_string(K),
+                    eflops + 2.0 * B * npix * exp * K * K, ((double)B * (Hi * Wi * curC + npix * exp) + (double)curC * exp) * es,
+                    [=](hipStream_t st, const FrameIO&) {
+                        if constexpr (std::is_same<T, float>::value) { if (split) { launch_ed<f32s>(a, B, K, st); return; } }
+                        launch_ed<T>(a, B, K, st);
+                    });
+                if (b.has_se) {
+                    // scale = hardsigmoid(fc2(relu(fc1(mean)))): the fc1 pre-activations arrive as per-block partials
+                    T* sc = abuf((size_t)B * exp);
+                    GemvArgs g2; memset(&g2, 0, sizeof g2);
+                    g2.xin = hpart; g2.nparts = nparts; g2.part_stride = b.se.S; g2.xscale = 1.f / (float)npix;
+                    g2.xbias = (const float*)(wb + b.se.b1); g2.xact = ACT_RELU;
+                    g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
+                    g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
+                    add("mb" + std::to_string(i + 1) + ".se_fc", 4.0 * B * exp * b.se.S, 2.0 * exp * b.se.S * es,
+                        [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
+                    scale = sc;
+                }
             }
             T* out = abuf((size_t)B * npix * b.row.cout);
             pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);

@@ -476,30 +476,224 @@ template void launch_dw<f16>(const DwArgs&, int, int, hipStream_t);
 template void launch_dw<float>(const DwArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
+// Fused inverted-residual front half: 1x1 expand (+BN+act) on the MFMA straight into an LDS tile,
+// depthwise k x k (+BN+act) out of that tile, and - for squeeze-excite blocks - the block's share of
+// the SE average pool pushed through fc1 (fc1 is linear before its ReLU, so per-block partial
+// pre-activations simply add up).  Replaces torchvision InvertedResidual's first two
+// ConvBNActivation units and the pooling half of SqueezeExcitation (reference
+// model/mobilenetv3.py:39-58).  The expanded tensor never goes to memory.
+// Block = 16 expanded channels x a band of output rows (full width), 1024 threads:
+//   E: the band's input rows form one contiguous pixel range; wave w runs the 16-pixel m-tiles
+//      w, w+16, ... with all K steps of a tile loaded at once; results go to LDS as
+//      [channel quad][pixel][4] so the depthwise reads are conflict-free.
+//   D: a wave owns one channel quad (uniform weights, LDS broadcast) x 64 consecutive output pixels.
+// ------------------------------------------------------------------------------------------
+constexpr int ED_KSMAX = 5;                                  // Cin <= 160
+size_t ed_lds_bytes(int K, int KS, int npxs, int es) {
+    return (size_t)4 * npxs * 16 + (size_t)KS * 512 * es + (size_t)(K * K * 16 + 32 + 16) * 4 + 4096;
+}
+template <typename T, int K>
+__global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x, band = blockIdx.y, n = blockIdx.z;
+    const int c0 = slice * 16;
+    const int r0 = band * a.rb, r1 = min(r0 + a.rb, a.Ho);
+    const int in_lo = max(r0 * a.stride - a.pad, 0);
+    const int in_hi = min((r1 - 1) * a.stride - a.pad + (K - 1) * a.dil, a.Hi - 1);
+    const int NPX = (in_hi - in_lo + 1) * a.Wi;
+    f32x4* ebuf = (f32x4*)smem;                                      // [4][npxs]
+    T* we = (T*)(ebuf + 4 * a.npxs);                                 // [KS][512]
+    float* wd = (float*)(we + (size_t)a.KS * 512);                   // [K*K][16]
+    float* bd = wd + K * K * 16;                                     // [16]
+    float* be = bd + 16;                                             // [16]
+    float* psum = be + 16;                                           // [16]
+    f32x4* red = (f32x4*)(psum + 16);                                // [<= 256] per-wave-item partial sums
+    const T* xb = (const T*)a.x + ((size_t)n * a.Hi + in_lo) * a.Wi * a.xs;
+
+    // ---- E: expand into the LDS tile.  The first m-tile's pixel loads are issued before the weights are
+    //      staged so that both round trips to L2 overlap.
+    const int MT = (NPX + 15) >> 4;
+    Frag<T> xf[ED_KSMAX];
+    auto load_x = [&](int mt) {
+        const int px = mt * 16 + l15;
+        const bool pv = px < NPX;
+        const T* xp = xb + (size_t)(pv ? px : 0) * a.xs + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < ED_KSMAX; ++ks) {
+            if (ks < a.KS && pv && ks * 32 + g * 8 < a.Cin) xf[ks].load(xp + ks * 32);
+            else xf[ks].zero();
+        }
+    };
+    if (a.w && wave < MT) load_x(wave);
+    // weights of this channel slice into LDS
+    {
+        f32x4 wreg[2];
+        const int pieces = a.w ? a.KS * 512 * (int)sizeof(T) / 16 : 0;         // <= 5 * 128 = 640 < 1024
+        const char* src = (const char*)a.w + (size_t)slice * a.KS * 512 * sizeof(T);
+        if (tid < pieces) wreg[0] = *(const f32x4*)(src + (size_t)tid * 16);
+        float dwv = 0.f, bdv = 0.f, bev = 0.f;
+        if (tid < K * K * 16) { const int c = c0 + (tid & 15); if (c < a.C) dwv = a.dw_w[(size_t)(tid >> 4) * a.C + c]; }
+        if (tid >= 1024 - 16) {
+            const int c = c0 + (tid & 15);
+            if (c < a.C) bdv = a.dw_b[c];
+            if (a.w) bev = a.ebias[c];
+        }
+        if (tid < pieces) *(f32x4*)((char*)we + (size_t)tid * 16) = wreg[0];
+        if (tid < K * K * 16) wd[tid] = dwv;
+        if (tid >= 1024 - 16) { bd[tid & 15] = bdv; be[tid & 15] = bev; }
+    }
+    __syncthreads();
+    if (a.w) {
+        for (int mt = wave; mt < MT; mt += 16) {
+            if (mt != wave) load_x(mt);
+            const int px = mt * 16 + l15;
+            f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < ED_KSMAX; ++ks) {
+                if (ks < a.KS) {
+                    Frag<T> wf;
+                    wf.loadw(we + (size_t)ks * 512, lane);
+                    mma(acc, wf, xf[ks]);
+                }
+            }
+            f32x4 v = acc + *(const f32x4*)(be + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.eact);
+            if (px < NPX) ebuf[g * a.npxs + px] = v;
+        }
+    } else {
+        for (int it = tid; it < NPX * 4; it += 1024) {
+            const int px = it >> 2, q = it & 3;
+            ebuf[q * a.npxs + px] = (c0 + q * 4 < a.C) ? ld4f(xb + (size_t)px * a.xs + c0 + q * 4) : f32x4{0, 0, 0, 0};
+        }
+    }
+    __syncthreads();
+
+    // ---- D: depthwise conv out of the tile
+    const int npo = (r1 - r0) * a.Wo;
+    const int npo_pad = (npo + 63) & ~63;
+    const int wpq = npo_pad >> 6;                                    // wave-items per channel quad
+    T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C;
+    for (int it = tid; it < 4 * npo_pad; it += 1024) {
+        const int q = it / npo_pad, p = it - q * npo_pad;            // q is wave-uniform
+        const bool valid = p < npo;
+        const int pp = valid ? p : 0;
+        const int oyl = pp / a.Wo, ox = pp - oyl * a.Wo;
+        const int iy0 = (r0 + oyl) * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        const f32x4* eq = ebuf + q * a.npxs;
+        f32x4 acc = *(const f32x4*)(bd + q * 4);
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {                             // one tap row in flight at a time (registers)
+            const int iy = iy0 + ky * a.dil;
+            const int iyc = min(max(iy, in_lo), in_hi);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ix0 + kx * a.dil;
+                const int ixc = min(max(ix, 0), a.Wi - 1);
+                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+                const f32x4 v = eq[(iyc - in_lo) * a.Wi + ixc];
+                acc += (v * m) * *(const f32x4*)(wd + (ky * K + kx) * 16 + q * 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = act_f(acc[r], a.dact);
+        const bool cok = c0 + q * 4 < a.C;
+        if (valid && cok) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
+        if (a.hpart) {
+            f32x4 s = valid ? acc : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], m);
+            }
+            if (lane == 0) red[it >> 6] = s;                         // slot = q * wpq + (p >> 6)
+        }
+    }
+    if (a.hpart) {
+        __syncthreads();
+        if (tid < 16) {
+            const int q = tid >> 2, r = tid & 3;
+            float s = 0.f;
+            for (int j = 0; j < wpq; ++j) s += red[q * wpq + j][r];
+            psum[tid] = (c0 + tid < a.C) ? s : 0.f;
+        }
+        __syncthreads();
+        // fc1 partial: h[s] += sum_c W1[s][c0 + c] * psum[c]
+        const int nparts = gridDim.x * a.nband;
+        float* hp = a.hpart + ((size_t)n * nparts + slice * a.nband + band) * a.S;
+        for (int sidx = tid; sidx < a.S; sidx += 1024) {
+            const float* wr = a.fc1_w + (size_t)sidx * a.C + c0;
+            float h = 0.f;
+            if (c0 + 16 <= a.C) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = *(const f32x4*)(wr + q * 4);
+                    h += w4[0] * psum[q * 4] + w4[1] * psum[q * 4 + 1] + w4[2] * psum[q * 4 + 2] + w4[3] * psum[q * 4 + 3];
+                }
+            } else {
+                for (int c = 0; c0 + c < a.C; ++c) h += wr[c] * psum[c];
+            }
+            hp[sidx] = h;
+        }
+    }
+}
+template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s) {
+    dim3 grid((a.C + 15) / 16, a.nband, N);
+    const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
+    if (K == 3) hipLaunchKernelGGL((mbconv_ed<T, 3>), grid, dim3(1024), lds, s, a);
+    else hipLaunchKernelGGL((mbconv_ed<T, 5>), grid, dim3(1024), lds, s, a);
+}
+template void launch_ed<f16>(const EdArgs&, int, int, hipStream_t);
+template void launch_ed<float>(const EdArgs&, int, int, hipStream_t);
+template void launch_ed<f32s>(const EdArgs&, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
 // Dense layer on a pooled vector: SE fc1 (+ReLU), fc2 (+hardsigmoid) and the LR-ASPP gate
 // (global mean -> 1x1 conv -> sigmoid, lraspp.py:11-15).  The input vector is first reduced
 // from per-block partial sums (fixed order => deterministic).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void gemv_act(GemvArgs a) {
+__global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < a.I; i += 256) {
+    __shared__ float part[1024];
+    const int n = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
+    // x[i] = act(xscale * sum_p xin[p][i] + xbias[i]); the partial rows are summed in a fixed order with
+    // 16 loads in flight; short vectors use G = 256 / I thread groups that each take every G-th row.
+    auto psum = [&](int i, int p0, int G) {
         const float* xp = a.xin + (size_t)n * a.nparts * a.part_stride + i;
         float s = 0.f;
-        int p = 0;
-        for (; p + 8 <= a.nparts; p += 8) {          // 8 independent loads in flight, fixed summation order
-            float v[8];
+        int p = p0;
+        for (; p + 15 * G < a.nparts; p += 16 * G) {
+            float v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = xp[(size_t)(p + j) * a.part_stride];
-            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            for (int j = 0; j < 16; ++j) v[j] = xp[(size_t)(p + j * G) * a.part_stride];
+            s += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])))
+               + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         }
-        for (; p < a.nparts; ++p) s += xp[(size_t)p * a.part_stride];
-        xs[i] = s * a.xscale;
+        for (; p < a.nparts; p += G) s += xp[(size_t)p * a.part_stride];
+        return s;
+    };
+    auto fin = [&](float s, int i) {
+        s *= a.xscale;
+        if (a.xbias) s = act_f(s + a.xbias[i], a.xact);
+        return s;
+    };
+    if (a.I >= NTH || a.nparts == 1) {
+        for (int i = tid; i < a.I; i += NTH) xs[i] = fin(psum(i, 0, 1), i);
+    } else {
+        const int G = min(NTH / a.I, a.nparts);
+        if (tid < G * a.I) part[tid] = psum(tid % a.I, tid / a.I, G);
+        __syncthreads();
+        if (tid < a.I) {
+            float s = 0.f;
+            for (int gq = 0; gq < G; ++gq) s += part[gq * a.I + tid];
+            xs[tid] = fin(s, tid);
+        }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int o0 = (blockIdx.x * 4 + wave) * a.opw;     // opw <= 4 outputs per wave, rows loaded together
+    const int o0 = (blockIdx.x * (NTH >> 6) + wave) * a.opw;     // opw <= 4 outputs per wave, rows loaded together
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane * 8; i < a.I; i += 512) {
         const f32x4 x0 = *(const f32x4*)(xs + i), x1 = *(const f32x4*)(xs + i + 4);
@@ -527,8 +721,10 @@ __global__ __launch_bounds__(256) void gemv_act(GemvArgs a) {
     }
 }
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) {
-    const int opb = 4 * a.opw;
-    hipLaunchKernelGGL((gemv_act<T>), dim3((a.O + opb - 1) / opb, N), dim3(256), (size_t)a.I * sizeof(float), s, a);
+    // many partial rows (SE fc1 partials, pooled ASPP input): 1024 threads so that one round of loads covers them
+    const int nth = a.nparts > 16 ? 1024 : 256;
+    const int opb = (nth / 64) * a.opw;
+    hipLaunchKernelGGL((gemv_act<T>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
 }
 template void launch_gemv<f16>(const GemvArgs&, int, hipStream_t);
 template void launch_gemv<float>(const GemvArgs&, int, hipStream_t);
@@ -1265,4 +1461,10 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
