@@ -67,6 +67,7 @@ struct EdArgs {
     int C, Hi, Wi, Ho, Wo, stride, dil, pad;
     int rb, nband;                          // output rows per band, number of bands
     int npxs;                               // pixels per channel-quad plane of the LDS tile (>= rows*Wi of any band, multiple of 16)
+    int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
 // ---- small dense layer on pooled vectors (SE fc1/fc2, LR-ASPP gate) ------------------------
@@ -142,4 +143,5 @@ size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
 template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s);
 size_t ed_lds_bytes(int K, int KS, int npxs, int es);
+int stamps_read(unsigned long long* out, unsigned int* nlaunch);   // in-kernel timeline (RVM_STAMPS builds)
 void kernels_init();   // one-time function attributes (dynamic LDS limits)

@@ -729,6 +729,7 @@ int build_plan(rvm_ctx* c) {
                 a.dw_w = (const float*)(wb + b.dw.w); a.dw_b = (const float*)(wb + b.dw.bias); a.dact = b.dw.act;
                 a.y = dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
                 a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(rows_for(rb) * Wi, 16);
+                { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
                 if (a.KS > 5 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024) return fail("mbconv_ed: unsupported block shape");
                 const int nparts = nslice * a.nband;
                 float* hpart = nullptr;
@@ -1119,6 +1120,14 @@ int rvm_profile_frame(rvm_ctx* c, const void* src, const void* const r_in[4], vo
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]));
     for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
+    if (!out || capacity < 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 512*16 values");
+    unsigned int n = 0;
+    if (stamps_read((unsigned long long*)out, &n)) return fail("rvm_debug_stamps: copy failed");
+    *nlaunch = (int)n;
     return 0;
 }
 

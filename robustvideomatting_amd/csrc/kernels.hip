@@ -14,6 +14,37 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------------------------------
+// Optional in-kernel timeline (build with -DRVM_STAMPS -> librvm_mi355x_stamps.so, tools/stamp_table.py):
+// thread 0 of block 0 of every launch takes the next slot of g_stamp and records the 100 MHz wall
+// clock at kernel start plus shader-clock stamps at phase boundaries.  Compiled out in the product.
+// ------------------------------------------------------------------------------------------
+#ifdef RVM_STAMPS
+__device__ unsigned long long g_stamp[512 * 16];
+__device__ unsigned int g_nlaunch;
+struct Stamper {
+    int base;
+    __device__ __forceinline__ Stamper() : base(-1) {
+        if ((blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0) {
+            base = (int)(atomicAdd(&g_nlaunch, 1u) & 511u) * 16;
+            for (int k = 2; k < 16; ++k) g_stamp[base + k] = 0;
+            g_stamp[base] = wall_clock64();
+            g_stamp[base + 1] = clock64();
+        }
+    }
+    __device__ __forceinline__ void operator()(int k) { if (base >= 0) g_stamp[base + 1 + k] = clock64(); }
+};
+int stamps_read(unsigned long long* out, unsigned int* nlaunch) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 512 * 16) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(nlaunch, HIP_SYMBOL(g_nlaunch), sizeof(unsigned int)) != hipSuccess) return 1;
+    return 0;
+}
+#else
+struct Stamper { __device__ __forceinline__ void operator()(int) const {} };
+int stamps_read(unsigned long long*, unsigned int* nlaunch) { *nlaunch = 0; return 0; }
+#endif
+
+// ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
 struct F8 { f32x4 lo, hi; };
@@ -151,6 +182,7 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-
 // instead of a 30-step one per wave).
 template <typename T, int MW, int NW, int WM, int WN, int KSP>
 __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = KSP > 1 ? 0 : wave % WM, wn = KSP > 1 ? 0 : wave / WM;
     const int mt0 = (blockIdx.x * (KSP > 1 ? 1 : WM) + wm) * MW;
@@ -222,6 +254,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
         }
     }
 
+    stamp(1);
     if constexpr (KSP > 1) {
         // fixed-order reduction of the 4 partial accumulators; tile t of the group is finished by wave t % 4
         __shared__ f32x4 red[KSP][MW * NW][64];
@@ -278,6 +311,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
             }
         }
     }
+    stamp(2);
 }
 
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
@@ -308,6 +342,7 @@ template void launch_pw<f32s>(const PwArgs&, int, int, hipStream_t);
 // ------------------------------------------------------------------------------------------
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_conv(DwArgs a) {
+    [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int cgl = threadIdx.x, CGB = blockDim.x, py = threadIdx.y, PY = blockDim.y, n = blockIdx.z;
     const int cg = blockIdx.x * CGB + cgl;
@@ -371,6 +406,7 @@ __global__ __launch_bounds__(256) void dw_conv(DwArgs a) {
 // channels is complete in one block (one partial row).
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_conv_lds(DwArgs a) {
+    [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, n = blockIdx.z;
     const int c = blockIdx.x * 8;
@@ -494,6 +530,7 @@ size_t ed_lds_bytes(int K, int KS, int npxs, int es) {
 }
 template <typename T, int K>
 __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
+    [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int slice = blockIdx.x, band = blockIdx.y, n = blockIdx.z;
@@ -525,7 +562,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             else xf[ks].zero();
         }
     };
-    if (a.w && wave < MT) load_x(wave);
+    if (a.w && wave < MT && !(a.dbg & 1)) load_x(wave);
     // weights of this channel slice into LDS
     {
         f32x4 wreg[2];
@@ -544,7 +581,8 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         if (tid >= 1024 - 16) { bd[tid & 15] = bdv; be[tid & 15] = bev; }
     }
     __syncthreads();
-    if (a.w) {
+    stamp(1);
+    if (a.w && !(a.dbg & 1)) {
         for (int mt = wave; mt < MT; mt += 16) {
             if (mt != wave) load_x(mt);
             const int px = mt * 16 + l15;
@@ -570,6 +608,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     }
     __syncthreads();
 
+    stamp(2);
     // ---- D: depthwise conv out of the tile
     const int npo = (r1 - r0) * a.Wo;
     const int npo_pad = (npo + 63) & ~63;
@@ -584,7 +623,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         const f32x4* eq = ebuf + q * a.npxs;
         f32x4 acc = *(const f32x4*)(bd + q * 4);
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {                             // one tap row in flight at a time (registers)
+        for (int ky = 0; ky < ((a.dbg & 2) ? 0 : K); ++ky) {         // one tap row in flight at a time (registers)
             const int iy = iy0 + ky * a.dil;
             const int iyc = min(max(iy, in_lo), in_hi);
 #pragma unroll
@@ -599,7 +638,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = act_f(acc[r], a.dact);
         const bool cok = c0 + q * 4 < a.C;
-        if (valid && cok) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
+        if (valid && cok && !(a.dbg & 4)) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
         if (a.hpart) {
             f32x4 s = valid ? acc : f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -610,6 +649,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             if (lane == 0) red[it >> 6] = s;                         // slot = q * wpq + (p >> 6)
         }
     }
+    stamp(3);
     if (a.hpart) {
         __syncthreads();
         if (tid < 16) {
@@ -637,6 +677,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             hp[sidx] = h;
         }
     }
+    stamp(4);
 }
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s) {
     dim3 grid((a.C + 15) / 16, a.nband, N);
@@ -655,6 +696,7 @@ template void launch_ed<f32s>(const EdArgs&, int, int, hipStream_t);
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
+    [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ float part[1024];
     const int n = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
@@ -664,14 +706,17 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
         const float* xp = a.xin + (size_t)n * a.nparts * a.part_stride + i;
         float s = 0.f;
         int p = p0;
-        for (; p + 15 * G < a.nparts; p += 16 * G) {
+        for (; p < a.nparts; p += 16 * G) {                  // all 16 loads of a round in flight (clamped + masked tail)
             float v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = xp[(size_t)(p + j * G) * a.part_stride];
+            for (int j = 0; j < 16; ++j) {
+                const int pj = p + j * G;
+                const float t = xp[(size_t)min(pj, a.nparts - 1) * a.part_stride];
+                v[j] = pj < a.nparts ? t : 0.f;
+            }
             s += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])))
                + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         }
-        for (; p < a.nparts; p += G) s += xp[(size_t)p * a.part_stride];
         return s;
     };
     auto fin = [&](float s, int i) {
@@ -692,6 +737,7 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
         }
     }
     __syncthreads();
+    stamp(1);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o0 = (blockIdx.x * (NTH >> 6) + wave) * a.opw;     // opw <= 4 outputs per wave, rows loaded together
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -719,6 +765,7 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
             else ((float*)a.y)[(size_t)n * a.O + o] = s;
         }
     }
+    stamp(2);
 }
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) {
     // many partial rows (SE fc1 partials, pooled ASPP input): 1024 threads so that one round of loads covers them
@@ -820,6 +867,7 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
 // K index inside a chunk = tap * chunk_channels + channel.
 template <typename T, int MW, int NW, int KD, int S, int D>
 __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
+    [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* patch = (T*)smem;
     typedef ConvGeo<MW, KD, S, D> G;
@@ -904,6 +952,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
         }
         if (chunk == 0) wstore(0);
         __syncthreads();
+        if (chunk == 0) stamp(1);
 
         // ---- implicit GEMM over this chunk, SK steps per weight stage ----
         const int NQ8 = CCc >> 3;
@@ -940,6 +989,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
     }
 
     // ---- epilogue ----
+    stamp(2);
     const int gx = x0 + l15;
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
@@ -990,6 +1040,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
             }
         }
     }
+    stamp(3);
 }
 
 template <typename T, int MW, int NW, int KD, int S, int D>
@@ -1021,6 +1072,7 @@ template void launch_conv3<f32s>(const ConvArgs&, int, int, int, int, hipStream_
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv(StemArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (p >= a.Ho * a.Wo) return;
     const int oy = p / a.Wo, ox = p - oy * a.Wo;
@@ -1070,6 +1122,7 @@ template void launch_stem<float>(const StemArgs&, int, hipStream_t);
 // AvgPool pyramid, decoder.py:33-36: 2x2, ceil_mode, count_include_pad=False).
 template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (p >= a.h1 * a.w1) return;
     const int py = p / a.w1, px = p - py * a.w1;
@@ -1118,6 +1171,7 @@ template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
 // 4x4 s1 pixels under it into 2x2 s2 pixels, stores them, and averages those into s3.
 template <typename T>
 __global__ __launch_bounds__(256) void pyramid23(PoolArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (p >= a.H3 * a.W3) return;
     const int y3 = p / a.W3, x3 = p - y3 * a.W3;
@@ -1161,6 +1215,7 @@ template void launch_pool<float>(const PoolArgs&, int, hipStream_t);
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dgf_lowres(DgfLowArgs a) {
+    [[maybe_unused]] Stamper stamp;
     __shared__ f32x4 sx[18 * 18], sy[18 * 18];
     const DgfWeights& wt = *a.wt;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
@@ -1279,6 +1334,7 @@ template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
 // ------------------------------------------------------------------------------------------
 template <typename TIO>
 __global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
     const int y = blockIdx.y, n = blockIdx.z;
     if (x0 >= a.W) return;
@@ -1374,6 +1430,7 @@ template void launch_dgf_apply<float>(const DgfApplyArgs&, int, bool, hipStream_
 // ------------------------------------------------------------------------------------------
 template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     const int HW = a.H * a.W;
     if (p >= HW) return;
@@ -1416,6 +1473,7 @@ template void launch_proj_out<float>(const ProjOutArgs&, int, bool, hipStream_t)
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3s2(MaxPoolArgs a) {
+    [[maybe_unused]] Stamper stamp;
     const int CG = a.C >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (idx >= a.Ho * a.Wo * CG) return;

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librvm_mi355x.so")
+# RVM_LIB_VARIANT=stamps selects the instrumented build (in-kernel timeline, tuning only)
+_VARIANT = os.environ.get("RVM_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "lib", "librvm_mi355x%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
 DTYPE_F32, DTYPE_F16, DTYPE_F16IO = 0, 1, 2
 VARIANTS = {"mobilenetv3": 0, "resnet50": 1}
@@ -17,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_state_shape", "rvm_forward",
-    "rvm_debug_tap", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -62,6 +64,8 @@ def lib():
     L.rvm_forward.restype = ci
     L.rvm_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64, i64p]
     L.rvm_debug_tap.restype = ci
+    L.rvm_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ci, ctypes.POINTER(ci)]
+    L.rvm_debug_stamps.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
     L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
@@ -77,6 +81,14 @@ def lib():
     L.rvm_version.restype = ctypes.c_char_p
     _lib = L
     return L
+
+
+def debug_stamps():
+    """(nlaunch, [512][16] uint64) from the RVM_STAMPS build; nlaunch == 0 in the product build."""
+    buf = (ctypes.c_uint64 * (512 * 16))()
+    n = ctypes.c_int()
+    check(lib().rvm_debug_stamps(buf, 512 * 16, ctypes.byref(n)), "rvm_debug_stamps")
+    return n.value, [list(buf[i * 16:(i + 1) * 16]) for i in range(512)]
 
 
 def check(rc, what=""):
