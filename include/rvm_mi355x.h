@@ -66,10 +66,11 @@ int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* 
  * Names: s0 s1 s2 s3 f1 f2 f3 f4 aspp x3 x2 x1 hid ab.  Synchronises the device. */
 int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capacity, int64_t shape[4]);
 
-/* In-kernel timeline of the last <= 512 launches (16 values each: 100 MHz wall clock at kernel start,
- * shader-clock stamps at phase boundaries).  Only the RVM_STAMPS build of the library records them;
+/* In-kernel timeline of the last <= 512 launches, two tables of 512 x 16 values (block 0 of each launch,
+ * then the last block of each launch; per row: 100 MHz wall clock at block start, then shader-clock
+ * stamps at phase boundaries); nlaunch[2] = launches recorded per table.  Only the RVM_STAMPS build of the library records them;
  * the product build reports *nlaunch = 0.  Synchronises the device.  Tuning aid, tools/stamp_table.py. */
-int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch);
+int rvm_debug_stamps(uint64_t* out, int capacity, int nlaunch[2]);
 
 /* Number of kernel launches one rvm_forward enqueues for the current plan. */
 int rvm_launch_count(const rvm_ctx* ctx);

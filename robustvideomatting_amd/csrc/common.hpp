@@ -89,6 +89,7 @@ struct ConvArgs {
     int H, W, tiles_x, epi;                 // H, W: OUTPUT size
     int Hi, Wi;                             // input size of the direct (non-upsampled) sources
     int CC, nchunks;                        // channel chunk staged per pass (multiple of 8), number of passes
+    int SK, SKlog2;                         // K steps per weight stage in LDS (2, 4 or 8)
     void* y; int Cout; int ys;              // EPI_RELU
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
@@ -137,7 +138,7 @@ template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
-template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC);
+template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK);
 void dw_block_shape(int C, int* cgb, int* pyb);
 size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
 template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);

@@ -350,7 +350,8 @@ bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, in
 // NHWC4 image sources, get zero weights).
 size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     const int KD = geo == 3 ? 7 : 3, S = (geo == 1 || geo == 3) ? 2 : 1, D = geo == 2 ? 2 : 1;
-    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC);   // f32s == float
+    const int SK = c->dtype == RVM_DTYPE_F16 ? 4 : 2;
+    return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC, SK) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC, SK);   // f32s == float
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
                 const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0) {
@@ -647,6 +648,7 @@ int build_plan(rvm_ctx* c) {
         a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
         a.CC = L.CC; a.nchunks = L.nchunks;
         { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) : 0; }
+        const int SK0 = sizeof(T) == 2 ? 4 : 2;             // minimum weight stage depth (K steps)
         // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
         int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
         int MW = 1;
@@ -659,7 +661,7 @@ int build_plan(rvm_ctx* c) {
             for (int k = 0; k < 5; ++k) {
                 const int m = cand[k][0], nw = cand[k][1];
                 if (epi == EPI_GRU_IH && nw != 2) continue;
-                const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC);
+                const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC, SK0);
                 if (lds > 150 * 1024) continue;
                 const int occ = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
                 const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
@@ -671,7 +673,20 @@ int build_plan(rvm_ctx* c) {
             NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
             if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
         }
-        if (conv_lds_bytes<T>(MW, NW, L.KD, (geo == 1 || geo == 3) ? 2 : 1, geo == 2 ? 2 : 1, L.CC) > 160 * 1024) return fail("conv: input patch does not fit LDS");
+        const int cS = (geo == 1 || geo == 3) ? 2 : 1, cD = geo == 2 ? 2 : 1;
+        if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");
+        // weight stage depth: each stage costs one global round trip, so use the deepest that keeps the
+        // block count per CU the grid needs (one block per CU when the grid is small)
+        a.SK = SK0;
+        {
+            const int blocks = a.tiles_x * cdiv(Ho, 4 * MW) * cdiv(L.NT, NW) * B;
+            const size_t budget = blocks <= 256 ? 150 * 1024 : (blocks <= 512 ? 78 * 1024 : 52 * 1024);
+            const char* e = getenv("RVM_CONV_SK");
+            const int skmax = e ? atoi(e) : 8;
+            for (int sk = SK0 * 2; sk <= skmax; sk *= 2)
+                if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, sk) <= budget && (L.nchunks == 1 || sk <= 8)) a.SK = sk;
+            a.SKlog2 = a.SK == 8 ? 3 : (a.SK == 4 ? 2 : 1);
+        }
         const double KK = (double)L.KD * L.KD;
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
             ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es,
@@ -1124,10 +1139,10 @@ int rvm_profile_frame(rvm_ctx* c, const void* src, const void* const r_in[4], vo
 }
 
 int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
-    if (!out || capacity < 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 512*16 values");
-    unsigned int n = 0;
-    if (stamps_read((unsigned long long*)out, &n)) return fail("rvm_debug_stamps: copy failed");
-    *nlaunch = (int)n;
+    if (!out || capacity < 2 * 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 2*512*16 values");
+    unsigned int n[2] = {0, 0};
+    if (stamps_read((unsigned long long*)out, n)) return fail("rvm_debug_stamps: copy failed");
+    nlaunch[0] = (int)n[0]; nlaunch[1] = (int)n[1];
     return 0;
 }
 

@@ -19,29 +19,33 @@
 // clock at kernel start plus shader-clock stamps at phase boundaries.  Compiled out in the product.
 // ------------------------------------------------------------------------------------------
 #ifdef RVM_STAMPS
-__device__ unsigned long long g_stamp[512 * 16];
-__device__ unsigned int g_nlaunch;
+// table 0: block 0 of every launch; table 1: the LAST block of the grid (dispatched last, sees the loaded machine)
+__device__ unsigned long long g_stamp[2 * 512 * 16];
+__device__ unsigned int g_nlaunch[2];
 struct Stamper {
     int base;
     __device__ __forceinline__ Stamper() : base(-1) {
-        if ((blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0) {
-            base = (int)(atomicAdd(&g_nlaunch, 1u) & 511u) * 16;
-            for (int k = 2; k < 16; ++k) g_stamp[base + k] = 0;
-            g_stamp[base] = wall_clock64();
-            g_stamp[base + 1] = clock64();
-        }
+        if ((threadIdx.x | threadIdx.y) != 0) return;
+        int tab = -1;
+        if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0) tab = 0;
+        else if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) tab = 1;
+        if (tab < 0) return;
+        base = tab * 512 * 16 + (int)(atomicAdd(&g_nlaunch[tab], 1u) & 511u) * 16;
+        for (int k = 2; k < 16; ++k) g_stamp[base + k] = 0;
+        g_stamp[base] = wall_clock64();
+        g_stamp[base + 1] = clock64();
     }
     __device__ __forceinline__ void operator()(int k) { if (base >= 0) g_stamp[base + 1 + k] = clock64(); }
 };
 int stamps_read(unsigned long long* out, unsigned int* nlaunch) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 512 * 16) != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(nlaunch, HIP_SYMBOL(g_nlaunch), sizeof(unsigned int)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 2 * 512 * 16) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(nlaunch, HIP_SYMBOL(g_nlaunch), 2 * sizeof(unsigned int)) != hipSuccess) return 1;
     return 0;
 }
 #else
 struct Stamper { __device__ __forceinline__ void operator()(int) const {} };
-int stamps_read(unsigned long long*, unsigned int* nlaunch) { *nlaunch = 0; return 0; }
+int stamps_read(unsigned long long*, unsigned int* nlaunch) { nlaunch[0] = nlaunch[1] = 0; return 0; }
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -792,14 +796,17 @@ template <int MW, int KD, int S, int D> struct ConvGeo {
     static constexpr int PAD = (KD - 1) / 2 * D;
 };
 // LDS of one conv_kxk block: halo patch + double-buffered weight stages (SK K-steps x NW n-tiles)
-template <typename T> constexpr int conv_sk() { return sizeof(T) == 2 ? 4 : 2; }
-template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC) {
+constexpr int CONV_NT = 512;                                // threads per conv_kxk block
+constexpr int CONV_SKMAX = 8;                               // K steps per weight stage: 2, 4 or 8 (ConvArgs::SK)
+template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK) {
     const int PH = (4 * MW - 1) * S + (KD - 1) * D + 1, PW = 15 * S + (KD - 1) * D + 1;
-    return (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T) + (size_t)2 * conv_sk<T>() * NW * 512 * sizeof(T);
+    size_t patch = (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T);
+    if (patch < (size_t)MW * NW * 4096) patch = (size_t)MW * NW * 4096;     // the K-group reduction reuses the patch area
+    return patch + (size_t)2 * SK * NW * 512 * sizeof(T);
 }
-template size_t conv_lds_bytes<f16>(int, int, int, int, int, int);
-template size_t conv_lds_bytes<float>(int, int, int, int, int, int);
-template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int);
+template size_t conv_lds_bytes<f16>(int, int, int, int, int, int, int);
+template size_t conv_lds_bytes<float>(int, int, int, int, int, int, int);
+template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int, int);
 
 // Stage channel quads [q_lo, q_lo+q_cnt) of one source of the concatenated conv input into the
 // LDS halo patch (origin gy0,gx0 in source-resolution coordinates).  The (pixel, quad) items are
@@ -809,32 +816,32 @@ template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int);
 template <typename T, bool UP, bool HF, int PH, int PW>
 __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo, int q_cnt, int dst_c, int CSL, int n,
                                              int gy0, int gx0, int H, int W, int tid) {
-    constexpr int UN = UP ? 4 : 8;
+    constexpr int UN = UP ? 2 : 4;                         // x 512 threads: as many loads in flight per CU as 4 / 8 x 256
     const int QN = q_cnt;
     const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16 .. see below
     const int total = PH * PW * QN;
     constexpr bool hf = HF;                                  // compile-time: keeps the loads of a round branch-free
     const bool live = S.p != nullptr;
     if (!live) {                                             // no state yet (first frame): zeros
-        for (int it = tid; it < total; it += 256) {
+        for (int it = tid; it < total; it += CONV_NT) {
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
             stp4(patch + pp * CSL, dst_c + q * 4, f32x4{0, 0, 0, 0});
         }
         return;
     }
     const void* base = S.p;
-    for (int it0 = tid; it0 < total; it0 += 256 * UN) {
+    for (int it0 = tid; it0 < total; it0 += CONV_NT * UN) {
         f32x4 v[UN];
         int dst[UN], dch[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int it = min(it0 + u * 256, total - 1);
+            const int it = min(it0 + u * CONV_NT, total - 1);
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
             const int py = pp / PW, px = pp - py * PW;
             const int gy = gy0 + py, gx = gx0 + px;
             const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            dst[u] = (it0 + u * 256 < total) ? pp * CSL : -1;
+            dst[u] = (it0 + u * CONV_NT < total) ? pp * CSL : -1;
             dch[u] = dst_c + q * 4;
             {
                 if (!UP) {
@@ -866,16 +873,18 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
 // mobilenetv3 decoder; several for the resnet50 layers whose halo patch would not fit LDS);
 // K index inside a chunk = tap * chunk_channels + channel.
 template <typename T, int MW, int NW, int KD, int S, int D>
-__global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
+__global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* patch = (T*)smem;
     typedef ConvGeo<MW, KD, S, D> G;
     constexpr int TH = G::TH, PH = G::PH, PW = G::PW, KK = KD * KD;
-    constexpr int SK = conv_sk<T>();                        // K steps per weight stage
-    constexpr int WSTAGE = SK * NW * 512;                   // elements per stage
+    const int SK = a.SK;                                    // K steps per weight stage (2, 4 or 8; multiple of 2)
+    const int WSTAGE = SK * NW * 512;                       // elements per stage
     constexpr int EPP = 16 / sizeof(T);                     // elements per 16-byte piece
-    constexpr int NP = WSTAGE / EPP / 256;                  // pieces per thread per stage
+    constexpr int NPMAX = CONV_SKMAX * NW * 512 / EPP / CONV_NT;   // pieces per thread per stage, at most
+    const int NP = max(WSTAGE / EPP / CONV_NT, 1);          // (a stage smaller than one piece per thread is bounds-checked below)
+    const int npieces = WSTAGE / EPP;
     constexpr int PPS = 512 / EPP;                          // pieces per (step, tile) fragment
     const int CSL = a.CC + Tr<T>::kLdsPad;
     T* wbuf = patch + (size_t)PH * PW * CSL;                // [2][NW][SK][512]
@@ -885,7 +894,9 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
     const int H = a.H, W = a.W;                             // output size
     const int gy0 = y0 * S - G::PAD, gx0 = x0 * S - G::PAD; // patch origin in input coordinates
 
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    // 8 waves: wave & 3 = output row of the tile (m-tile), wave >> 2 = K group (even / odd K steps);
+    // the two groups' partial accumulators are added through LDS before the epilogue
+    const int wave = (tid >> 6) & 3, kgrp = tid >> 8, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NW;
     bool nv[NW];
 #pragma unroll
@@ -895,21 +906,28 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
     // all 256 threads), parked in registers while the previous stage is consumed, then written to
     // the other LDS buffer.  Every wave reads its fragments from LDS, so the L2 sees each weight
     // line once per block instead of once per wave.
-    f32x4 wr[NP];
+    f32x4 wr[NPMAX];
+    int wsx[NPMAX];                                         // K step of piece j inside a stage
+    unsigned wsrc[NPMAX];                                   // its source offset at step 0 (the weight blob is < 4 GiB)
+#pragma unroll
+    for (int j = 0; j < NPMAX; ++j) {
+        const int i = min(tid + CONV_NT * j, npieces - 1);
+        const int shf = a.SKlog2 + (EPP == 4 ? 7 : 6);      // log2(SK * PPS)
+        const int ni = i >> shf, rem = i - (ni << shf);
+        const int sidx = rem / PPS, r = rem - sidx * PPS;
+        const int tile = min(nt0 + ni, a.NT - 1);
+        wsx[j] = sidx;
+        wsrc[j] = (unsigned)(((size_t)tile * a.KS * 512) * sizeof(T) + (size_t)r * 16);
+    }
     auto wload = [&](int gs) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int i = tid + 256 * j;
-            const int ni = i / (SK * PPS), rem = i - ni * (SK * PPS);
-            const int sidx = rem / PPS, r = rem - sidx * PPS;
-            const int step = min(gs + sidx, a.KS - 1);
-            const int tile = min(nt0 + ni, a.NT - 1);
-            wr[j] = *(const f32x4*)((const char*)a.w + (((size_t)tile * a.KS + step) * 512) * sizeof(T) + (size_t)r * 16);
-        }
+        for (int j = 0; j < NPMAX; ++j)
+            if (j < NP) wr[j] = *(const f32x4*)((const char*)a.w + wsrc[j] + (size_t)min(gs + wsx[j], a.KS - 1) * (512 * sizeof(T)));
     };
     auto wstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + 256 * j) * 16) = wr[j];
+        for (int j = 0; j < NPMAX; ++j)
+            if (j < NP && tid + CONV_NT * j < npieces) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + CONV_NT * j) * 16) = wr[j];
     };
     wload(0);                                               // in flight while the patch is staged
 
@@ -946,7 +964,7 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
             }
             const int used = min(max(coff - c_lo, 0), CCc);  // zero the pad channels (weights there are 0, keep them finite)
             if (used < CCc) {
-                for (int pp = tid; pp < PH * PW; pp += 256)
+                for (int pp = tid; pp < PH * PW; pp += CONV_NT)
                     for (int cch = used; cch < CCc; cch += 4) stp4(patch + pp * CSL, cch, f32x4{0, 0, 0, 0});
             }
         }
@@ -956,14 +974,13 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
 
         // ---- implicit GEMM over this chunk, SK steps per weight stage ----
         const int NQ8 = CCc >> 3;
-        int tap = 0, c8 = g;
+        int tap = 0, c8 = g + 4 * kgrp;                          // K group 1 starts one step in
         while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
         for (int ks0 = 0; ks0 < ((a.dbg & 2) ? 0 : KSc); ks0 += SK) {
             const bool more = gs + SK < a.KS;
             if (more) wload(gs + SK);
             const T* wst = wbuf + (size_t)buf * WSTAGE;
-#pragma unroll
-            for (int p = 0; p < SK; ++p) {
+            for (int p = kgrp; p < SK; p += 2) {
                 if (ks0 + p < KSc && !(a.dbg & 4)) {
                     const int tp = min(tap, KK - 1);        // K tail: weights are zero there, keep the read in-bounds
                     const int dy = tp / KD, dx = tp - dy * KD;
@@ -977,15 +994,32 @@ __global__ __launch_bounds__(256) void conv_kxk(ConvArgs a) {
                     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
-                    c8 += 4;
-                    while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
                 }
+                c8 += 8;                                    // two K steps on
+                while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
             }
             if (more) wstore(buf ^ 1);
             __syncthreads();
             buf ^= 1;
             gs += SK;
         }
+    }
+
+    // ---- add the two K groups' accumulators (the patch area is free after the last barrier)
+    {
+        f32x4* red = (f32x4*)smem;                               // [4 rows][MW * NW][64]
+        if (kgrp == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NW; ++ni) red[(wave * MW * NW + mi * NW + ni) * 64 + lane] = acc[mi][ni];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[mi][ni] += red[(wave * MW * NW + mi * NW + ni) * 64 + lane];
     }
 
     // ---- epilogue ----
@@ -1048,7 +1082,7 @@ static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
-    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(256), conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC), s, a);
+    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(CONV_NT), conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.SK), s, a);
 }
 // geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {

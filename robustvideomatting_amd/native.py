@@ -84,11 +84,13 @@ def lib():
 
 
 def debug_stamps():
-    """(nlaunch, [512][16] uint64) from the RVM_STAMPS build; nlaunch == 0 in the product build."""
-    buf = (ctypes.c_uint64 * (512 * 16))()
-    n = ctypes.c_int()
-    check(lib().rvm_debug_stamps(buf, 512 * 16, ctypes.byref(n)), "rvm_debug_stamps")
-    return n.value, [list(buf[i * 16:(i + 1) * 16]) for i in range(512)]
+    """((n0, n1), table0, table1) from the RVM_STAMPS build: [512][16] uint64 rows of block 0 / the last
+    block of the most recent launches; counts are 0 in the product build."""
+    buf = (ctypes.c_uint64 * (2 * 512 * 16))()
+    n = (ctypes.c_int * 2)()
+    check(lib().rvm_debug_stamps(buf, 2 * 512 * 16, n), "rvm_debug_stamps")
+    tabs = [[list(buf[(t * 512 + i) * 16:(t * 512 + i + 1) * 16]) for i in range(512)] for t in range(2)]
+    return (n[0], n[1]), tabs[0], tabs[1]
 
 
 def check(rc, what=""):

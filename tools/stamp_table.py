@@ -42,11 +42,17 @@ def main():
     torch.cuda.synchronize()
     names = [n for n, _, _ in model._ctx.launch_info()]
     n = len(names)
-    total, st = native.debug_stamps()
+    (total, total1), st, st1 = native.debug_stamps()
     assert total > 0, "library was not built with RVM_STAMPS"
     assert total % n == 0, (total, n)
     nfr = min(512 // n - 1, a.frames - 2)
-    acc = [[0.0, [0.0] * 14] for _ in range(n)]
+    single = [i for i in range(n)]      # launches whose grid has one block never write table 1
+    acc = [[0.0, [0.0] * 14, [0.0] * 14, 0.0] for _ in range(n)]
+    # table 1 rows are counted separately: only launches with > 1 block appear, in launch order
+    multi = None
+    if total1 % (total // n) == 0:
+        per_frame1 = total1 // (total // n)
+        multi = per_frame1
     for f in range(nfr):
         first = total - (f + 1) * n            # launch counter value of this frame's launch 0
         for i in range(n):
@@ -57,10 +63,30 @@ def main():
             for k in range(14):
                 if s[2 + k] and s[1 + k]:
                     acc[i][1][k] += (s[2 + k] - s[1 + k]) / nfr
+    # match table-1 rows to launches by start time: the last block of launch i starts after block 0 of
+    # launch i and before block 0 of launch i+1
+    rows1 = sorted((r for r in st1 if r[0]), key=lambda r: r[0])
+    starts = sorted(((st[(total - 1 - j) % 512][0], (total - 1 - j) % n) for j in range(min(total, 512))), key=lambda t: t[0])
+    import bisect
+    keys = [t[0] for t in starts]
+    cnt = [0] * n
+    for r in rows1:
+        j = bisect.bisect_right(keys, r[0]) - 1
+        if j < 0:
+            continue
+        i = starts[j][1]
+        cnt[i] += 1
+        acc[i][3] += (r[0] - starts[j][0]) * 0.01
+        for k in range(14):
+            if r[2 + k] and r[1 + k]:
+                acc[i][2][k] += (r[2 + k] - r[1 + k])
     print("%d frames, %d launches, frame %.1f us" % (nfr, n, sum(x[0] for x in acc)))
     for i in range(n):
         ph = " ".join("%6.0f" % c for c in acc[i][1] if c)
-        print("  %-20s %6.2f us   block-0 phase cycles: %s" % (names[i], acc[i][0], ph))
+        ph1 = ""
+        if cnt[i]:
+            ph1 = "  | last block +%.1f us: " % (acc[i][3] / cnt[i]) + " ".join("%6.0f" % (c / cnt[i]) for c in acc[i][2] if c)
+        print("  %-20s %6.2f us   cycles: %s%s" % (names[i], acc[i][0], ph, ph1))
 
 
 if __name__ == "__main__":
