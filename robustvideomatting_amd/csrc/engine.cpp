@@ -8,6 +8,7 @@
 #include "../../include/rvm_mi355x.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -350,7 +351,7 @@ bool pack_pw(rvm_ctx* c, const std::string& wname, const Affine& af, int Cin, in
 // NHWC4 image sources, get zero weights).
 size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     const int KD = geo == 3 ? 7 : 3, S = (geo == 1 || geo == 3) ? 2 : 1, D = geo == 2 ? 2 : 1;
-    const int SK = c->dtype == RVM_DTYPE_F16 ? 4 : 2;
+    const int SK = 4;
     return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC, SK) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC, SK);   // f32s == float
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
@@ -369,7 +370,7 @@ bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout
     L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin; L.geo = geo; L.KD = geo == 3 ? 7 : 3;
     // one pass if the whole-channel halo patch fits comfortably, else channel chunks of <= 64 KiB
     L.CC = L.Cpad; L.nchunks = 1;
-    if (conv_lds(c, 1, geo, L.Cpad) > 96 * 1024) {
+    if (conv_lds(c, 1, geo, L.Cpad) > 150 * 1024) {
         int cc = L.Cpad;
         while (cc > 8 && conv_lds(c, 1, geo, cc) > 64 * 1024) cc -= 8;
         L.CC = cc; L.nchunks = cdiv(L.Cpad, cc);
@@ -648,7 +649,7 @@ int build_plan(rvm_ctx* c) {
         a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
         a.CC = L.CC; a.nchunks = L.nchunks;
         { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) : 0; }
-        const int SK0 = sizeof(T) == 2 ? 4 : 2;             // minimum weight stage depth (K steps)
+        int SK0 = 4;                                        // minimum weight stage depth: one 16-byte piece per thread at least
         // tile shape: biggest rows-per-block that still yields >= 256 blocks and fits LDS
         int NW = (L.NT >= 2 || epi == EPI_GRU_IH) ? 2 : 1;
         int MW = 1;
@@ -677,6 +678,8 @@ int build_plan(rvm_ctx* c) {
         if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");
         // weight stage depth: each stage costs one global round trip, so use the deepest that keeps the
         // block count per CU the grid needs (one block per CU when the grid is small)
+        if (SK0 * NW * 512 * (int)sizeof(T) < 16 * 512) SK0 = 8;                   // fp16, one n-tile
+        if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");
         a.SK = SK0;
         {
             const int blocks = a.tiles_x * cdiv(Ho, 4 * MW) * cdiv(L.NT, NW) * B;
@@ -686,6 +689,9 @@ int build_plan(rvm_ctx* c) {
             for (int sk = SK0 * 2; sk <= skmax; sk *= 2)
                 if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, sk) <= budget && (L.nchunks == 1 || sk <= 8)) a.SK = sk;
             a.SKlog2 = a.SK == 8 ? 3 : (a.SK == 4 ? 2 : 1);
+            if (getenv("RVM_VERBOSE") && c->arena)
+                fprintf(stderr, "[rvm] %-16s MW %d NW %d SK %d KS %d blocks %d lds %zu\n", name.c_str(), MW, NW, a.SK, L.KS, blocks,
+                        conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, a.SK));
         }
         const double KK = (double)L.KD * L.KD;
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,

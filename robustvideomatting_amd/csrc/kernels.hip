@@ -883,7 +883,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     const int WSTAGE = SK * NW * 512;                       // elements per stage
     constexpr int EPP = 16 / sizeof(T);                     // elements per 16-byte piece
     constexpr int NPMAX = CONV_SKMAX * NW * 512 / EPP / CONV_NT;   // pieces per thread per stage, at most
-    const int NP = max(WSTAGE / EPP / CONV_NT, 1);          // (a stage smaller than one piece per thread is bounds-checked below)
+    const int NP = WSTAGE / EPP / CONV_NT;                  // >= 1: the host keeps SK * NW * 512 >= EPP * CONV_NT
     const int npieces = WSTAGE / EPP;
     constexpr int PPS = 512 / EPP;                          // pieces per (step, tile) fragment
     const int CSL = a.CC + Tr<T>::kLdsPad;
@@ -896,7 +896,8 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
 
     // 8 waves: wave & 3 = output row of the tile (m-tile), wave >> 2 = K group (even / odd K steps);
     // the two groups' partial accumulators are added through LDS before the epilogue
-    const int wave = (tid >> 6) & 3, kgrp = tid >> 8, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), kgrp = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NW;
     bool nv[NW];
 #pragma unroll
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     auto wstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NPMAX; ++j)
-            if (j < NP && tid + CONV_NT * j < npieces) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + CONV_NT * j) * 16) = wr[j];
+            if (j < NP) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + CONV_NT * j) * 16) = wr[j];
     };
     wload(0);                                               // in flight while the patch is staged
 
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
         int tap = 0, c8 = g + 4 * kgrp;                          // K group 1 starts one step in
         while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
         for (int ks0 = 0; ks0 < ((a.dbg & 2) ? 0 : KSc); ks0 += SK) {
-            const bool more = gs + SK < a.KS;
+            const bool more = gs + SK < a.KS && !(a.dbg & 8);
             if (more) wload(gs + SK);
             const T* wst = wbuf + (size_t)buf * WSTAGE;
             for (int p = kgrp; p < SK; p += 2) {

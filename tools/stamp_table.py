@@ -80,7 +80,7 @@ def main():
         for k in range(14):
             if r[2 + k] and r[1 + k]:
                 acc[i][2][k] += (r[2 + k] - r[1 + k])
-    print("%d frames, %d launches, frame %.1f us" % (nfr, n, sum(x[0] for x in acc)))
+    print("RVM_DBG=%s  %d frames, %d launches, frame %.1f us" % (os.environ.get("RVM_DBG", ""), nfr, n, sum(x[0] for x in acc)))
     for i in range(n):
         ph = " ".join("%6.0f" % c for c in acc[i][1] if c)
         ph1 = ""
