@@ -123,6 +123,7 @@ struct DgfLowArgs { const void* hid; const void* s0; const DgfWeights* wt; float
 struct DgfApplyArgs {
     const void* src; const float* ab; void* fgr; void* pha;
     int H, W, h, w; float scale_y, scale_x;
+    int ncols;                              // low-res columns one 2048-px row segment can touch (LDS tile)
 };
 struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; void* fgr; void* pha; int H, W, seg; };
 

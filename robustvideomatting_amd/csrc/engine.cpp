@@ -931,6 +931,7 @@ int build_plan(rvm_ctx* c) {
         lo.fast = c->refiner == RVM_REFINER_FAST_GUIDED_FILTER;
         DgfApplyArgs ap; ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
+        ap.ncols = std::min(c->w, (int)std::ceil(2048.0 * ap.scale_x) + 3);
         ProjOutArgs po; po.hid = hid; po.wt = dw; po.H = c->h; po.W = c->w;
         const bool refine = c->ds != 1.0;
         const double lowpx = (double)B * c->h * c->w, fullpx = (double)B * c->H * c->W;

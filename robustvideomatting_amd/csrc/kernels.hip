@@ -1367,94 +1367,115 @@ template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
 // 37-39), out = A*[src,gray]+b (:41), fgr = clamp(out+src), pha = clamp(out) (model.py:65-67).
 // One pass: src read once, fgr/pha written once; a thread owns 8 consecutive x.
 // ------------------------------------------------------------------------------------------
+template <typename TIO> struct IoV8;
+template <> struct IoV8<f16> { typedef f16x8 type; };
+template <> struct IoV8<float> { typedef f32x8 type; };
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 8 output values of one channel, packed to the I/O type pair by pair as they are produced
+template <typename TIO> struct Out8;
+template <> struct Out8<f16> {
+    unsigned r[4];
+    __device__ __forceinline__ void set(int jp, float a, float b) { f16x2 p = {(f16)a, (f16)b}; r[jp] = __builtin_bit_cast(unsigned, p); }
+    __device__ __forceinline__ void store(f16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
+    __device__ __forceinline__ f16 get(int j) const { return __builtin_bit_cast(f16x2, r[j >> 1])[j & 1]; }
+};
+template <> struct Out8<float> {
+    float r[8];
+    __device__ __forceinline__ void set(int jp, float a, float b) { r[2 * jp] = a; r[2 * jp + 1] = b; }
+    __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = f32x4{r[0], r[1], r[2], r[3]}; *(f32x4*)(p + 4) = f32x4{r[4], r[5], r[6], r[7]}; }
+    __device__ __forceinline__ float get(int j) const { return r[j]; }
+};
+// Block = one segment of 2048 consecutive x of one row (256 threads x 8 px).  The A|b rows are first
+// interpolated vertically for the low-res columns the segment touches and parked in LDS
+// ([column][8] fp32), then every thread interpolates horizontally out of LDS, branch-free, and packs
+// its results to the I/O type pair by pair (few registers -> many rows in flight per CU).
 template <typename TIO>
 __global__ __launch_bounds__(256) void dgf_apply(DgfApplyArgs a) {
     [[maybe_unused]] Stamper stamp;
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    typedef typename IoV8<TIO>::type V8;
+    extern __shared__ __attribute__((aligned(16))) f32x4 colAB[];       // [ncols][2]
+    const int tid = threadIdx.x;
+    const int seg0 = blockIdx.x * 2048;
+    const int x0 = seg0 + tid * 8;
     const int y = blockIdx.y, n = blockIdx.z;
-    if (x0 >= a.W) return;
-    float sy = a.scale_y * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    int iy0 = (int)sy; if (iy0 > a.h - 1) iy0 = a.h - 1;
-    const int iy1 = iy0 + (iy0 < a.h - 1);
-    const float ly = sy - iy0;
-    const float* r0 = a.ab + ((size_t)n * a.h + iy0) * a.w * 8;
-    const float* r1 = a.ab + ((size_t)n * a.h + iy1) * a.w * 8;
     const size_t plane = (size_t)a.H * a.W;
     const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    TIO* pp = (TIO*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
+    const bool active = x0 < a.W;
     const bool full = (x0 + 8 <= a.W) && ((a.W & 7) == 0);
-    float s[3][8];
-    if (full) {
+    V8 s[3];
+    if (full) {                                                         // issued first: in flight during the LDS phase
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            F8 v = ld8f(sp + c * plane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s[c][j] = v.lo[j]; s[c][4 + j] = v.hi[j]; }
-        }
+        for (int c = 0; c < 3; ++c) s[c] = *(const V8*)(sp + c * plane);
     } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[c][j] = (x0 + j < a.W) ? (float)sp[c * plane + j] : 0.f;
+            for (int j = 0; j < 8; ++j) s[c][j] = (active && x0 + j < a.W) ? sp[c * plane + j] : (TIO)0;
     }
-    float of[3][8], op[8];
-    int c0 = -1, c1 = -1;
-    f32x4 A0, B0, A1, B1;
-    A0 = B0 = A1 = B1 = f32x4{0, 0, 0, 0};
-    auto col = [&](int i, f32x4& A, f32x4& B) {
-        const f32x4 ta = *(const f32x4*)(r0 + (size_t)i * 8), tb = *(const f32x4*)(r0 + (size_t)i * 8 + 4);
-        const f32x4 ba = *(const f32x4*)(r1 + (size_t)i * 8), bb = *(const f32x4*)(r1 + (size_t)i * 8 + 4);
-        A = (1.f - ly) * ta + ly * ba;
-        B = (1.f - ly) * tb + ly * bb;
-    };
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float sx = a.scale_x * (x0 + j + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-        int ix0 = (int)sx; if (ix0 > a.w - 1) ix0 = a.w - 1;
-        const int ix1 = ix0 + (ix0 < a.w - 1);
-        const float lx = sx - ix0;
-        if (ix0 != c0) {
-            if (ix0 == c1) { A0 = A1; B0 = B1; } else col(ix0, A0, B0);
-            c0 = ix0;
-        }
-        if (ix1 != c1) {
-            if (ix1 == c0) { A1 = A0; B1 = B0; } else col(ix1, A1, B1);
-            c1 = ix1;
-        }
-        const f32x4 A = (1.f - lx) * A0 + lx * A1, B = (1.f - lx) * B0 + lx * B1;
-        const float gray = (s[0][j] + s[1][j] + s[2][j]) / 3.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) of[c][j] = fminf(fmaxf(A[c] * s[c][j] + B[c] + s[c][j], 0.f), 1.f);
-        op[j] = fminf(fmaxf(A[3] * gray + B[3], 0.f), 1.f);
+    // ---- vertical interpolation of the columns this segment needs
+    float sy = a.scale_y * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    int iy0 = (int)sy; if (iy0 > a.h - 1) iy0 = a.h - 1;
+    const int iy1 = iy0 + (iy0 < a.h - 1);
+    const float ly = sy - iy0;
+    float sxb = a.scale_x * (seg0 + 0.5f) - 0.5f; if (sxb < 0.f) sxb = 0.f;
+    const int cbase = min((int)sxb, a.w - 1);
+    const f32x4* r0 = (const f32x4*)(a.ab + ((size_t)n * a.h + iy0) * a.w * 8);
+    const f32x4* r1 = (const f32x4*)(a.ab + ((size_t)n * a.h + iy1) * a.w * 8);
+    for (int i = tid; i < 2 * a.ncols; i += 256) {                      // item = (column, A or b half)
+        const int col = min(cbase + (i >> 1), a.w - 1);
+        const f32x4 t = r0[col * 2 + (i & 1)], u = r1[col * 2 + (i & 1)];
+        colAB[i] = (1.f - ly) * t + ly * u;
     }
+    __syncthreads();
+    if (!active) return;
+    Out8<TIO> of[3], op;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        float o[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * jp + e;
+            float sx = a.scale_x * (x0 + j + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            int ix0 = (int)sx; if (ix0 > a.w - 1) ix0 = a.w - 1;
+            const int ix1 = ix0 + (ix0 < a.w - 1);
+            const float lx = sx - ix0;
+            const int k0 = min(ix0 - cbase, a.ncols - 1), k1 = min(ix1 - cbase, a.ncols - 1);
+            const f32x4 A = (1.f - lx) * colAB[2 * k0] + lx * colAB[2 * k1];
+            const f32x4 B = (1.f - lx) * colAB[2 * k0 + 1] + lx * colAB[2 * k1 + 1];
+            const float sr = (float)s[0][j], sg = (float)s[1][j], sb = (float)s[2][j];
+            const float gray = (sr + sg + sb) / 3.f;
+            o[e][0] = fminf(fmaxf(A[0] * sr + B[0] + sr, 0.f), 1.f);
+            o[e][1] = fminf(fmaxf(A[1] * sg + B[1] + sg, 0.f), 1.f);
+            o[e][2] = fminf(fmaxf(A[2] * sb + B[2] + sb, 0.f), 1.f);
+            o[e][3] = fminf(fmaxf(A[3] * gray + B[3], 0.f), 1.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) of[c].set(jp, o[0][c], o[1][c]);
+        op.set(jp, o[0][3], o[1][3]);
+    }
+    TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
+    TIO* pp = (TIO*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
     if (full) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            F8 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v.lo[j] = of[c][j]; v.hi[j] = of[c][4 + j]; }
-            st8f(fp + c * plane, v);
-        }
-        F8 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v.lo[j] = op[j]; v.hi[j] = op[4 + j]; }
-        st8f(pp, v);
+        for (int c = 0; c < 3; ++c) of[c].store(fp + c * plane);
+        op.store(pp);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (x0 + j < a.W) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) fp[c * plane + j] = (TIO)of[c][j];
-                pp[j] = (TIO)op[j];
+                for (int c = 0; c < 3; ++c) fp[c * plane + j] = of[c].get(j);
+                pp[j] = op.get(j);
             }
         }
     }
 }
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s) {
-    const int groups = (a.W + 7) / 8;
-    if (sizeof(T) == 2 || io16) hipLaunchKernelGGL((dgf_apply<f16>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dgf_apply<float>), dim3((groups + 255) / 256, a.H, N), dim3(256), 0, s, a);
+    const dim3 grid((a.W + 2047) / 2048, a.H, N);
+    const size_t lds = (size_t)a.ncols * 32;
+    if (sizeof(T) == 2 || io16) hipLaunchKernelGGL((dgf_apply<f16>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dgf_apply<float>), grid, dim3(256), lds, s, a);
 }
 template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, bool, hipStream_t);
 template void launch_dgf_apply<float>(const DgfApplyArgs&, int, bool, hipStream_t);
@@ -1554,6 +1575,8 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
+    (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
