@@ -698,14 +698,38 @@ template void launch_ed<f32s>(const EdArgs&, int, int, hipStream_t);
 // (global mean -> 1x1 conv -> sigmoid, lraspp.py:11-15).  The input vector is first reduced
 // from per-block partial sums (fixed order => deterministic).
 // ------------------------------------------------------------------------------------------
+// v + (value of the lane `n` places below in the same row of 16 lanes, 0 if none): DPP row_shr
+template <int N> __device__ __forceinline__ float row_shr_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+// Block = NTH/64 waves; a wave owns 4 outputs, one per row of 16 lanes; lane `sub` of a row takes the
+// 4-element chunks sub, sub+16, ... of the weight row (coalesced 256 B per row and round).  The weight
+// chunks and the bias are requested before the input vector is reduced, so the two global round trips
+// overlap; the dot products finish with 4 DPP adds.
 template <typename T>
 __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ float part[1024];
     const int n = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, row = lane >> 4, sub = lane & 15;
+    const int o = (blockIdx.x * (NTH >> 6) + wave) * 4 + row;
+    const bool ov = o < a.O;
+    const int nchunk = a.I >> 2;                                     // I % 4 == 0 (host-checked)
+    const T* wrow = (const T*)a.w + (size_t)(ov ? o : 0) * a.I;
+    f32x4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int c = sub + 16 * t;
+        w[t] = ld4f(wrow + 4 * min(c, nchunk - 1));
+        if (!(ov && c < nchunk)) w[t] = f32x4{0, 0, 0, 0};
+    }
+    const float bias = (a.bias && ov) ? a.bias[o] : 0.f;
+    const float xb = (a.xbias && tid < a.I) ? a.xbias[tid] : 0.f;      // needed after the partial-row reduction (I < NTH case)
+
     // x[i] = act(xscale * sum_p xin[p][i] + xbias[i]); the partial rows are summed in a fixed order with
-    // 16 loads in flight; short vectors use G = 256 / I thread groups that each take every G-th row.
+    // 16 loads in flight; short vectors use G = NTH / I thread groups that each take every G-th row.
     auto psum = [&](int i, int p0, int G) {
         const float* xp = a.xin + (size_t)n * a.nparts * a.part_stride + i;
         float s = 0.f;
@@ -737,44 +761,44 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
         if (tid < a.I) {
             float s = 0.f;
             for (int gq = 0; gq < G; ++gq) s += part[gq * a.I + tid];
-            xs[tid] = fin(s, tid);
+            s *= a.xscale;
+            xs[tid] = a.xbias ? act_f(s + xb, a.xact) : s;
         }
     }
     __syncthreads();
     stamp(1);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int o0 = (blockIdx.x * (NTH >> 6) + wave) * a.opw;     // opw <= 4 outputs per wave, rows loaded together
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = lane * 8; i < a.I; i += 512) {
-        const f32x4 x0 = *(const f32x4*)(xs + i), x1 = *(const f32x4*)(xs + i + 4);
+    float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < a.opw && o0 + k < a.O) {
-                F8 wv = ld8f((const T*)a.w + (size_t)(o0 + k) * a.I + i);
-                acc[k] += wv.lo[0] * x0[0] + wv.lo[1] * x0[1] + wv.lo[2] * x0[2] + wv.lo[3] * x0[3]
-                        + wv.hi[0] * x1[0] + wv.hi[1] * x1[1] + wv.hi[2] * x1[2] + wv.hi[3] * x1[3];
+    for (int t = 0; t < 16; ++t) {
+        const int c = min(sub + 16 * t, nchunk - 1);
+        const f32x4 x = *(const f32x4*)(xs + 4 * c);
+        acc += (w[t][0] * x[0] + w[t][1] * x[1]) + (w[t][2] * x[2] + w[t][3] * x[3]);
+    }
+    for (int base = 256; base < nchunk; base += 256) {               // rows longer than 1024 elements
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int c = base + sub + 16 * t;
+            if (ov && c < nchunk) {
+                const f32x4 wv = ld4f(wrow + 4 * c), x = *(const f32x4*)(xs + 4 * c);
+                acc += (wv[0] * x[0] + wv[1] * x[1]) + (wv[2] * x[2] + wv[3] * x[3]);
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float s = acc[k];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        const int o = o0 + k;
-        if (lane == 0 && k < a.opw && o < a.O) {
-            if (a.bias) s += a.bias[o];
-            s = act_f(s, a.act);
-            if (a.y_is_T) ((T*)a.y)[(size_t)n * a.O + o] = (T)s;
-            else ((float*)a.y)[(size_t)n * a.O + o] = s;
-        }
+    acc = row_shr_add<1>(acc);
+    acc = row_shr_add<2>(acc);
+    acc = row_shr_add<4>(acc);
+    acc = row_shr_add<8>(acc);                                       // lane 15 of the row holds the sum
+    if (sub == 15 && ov) {
+        const float r = act_f(acc + bias, a.act);
+        if (a.y_is_T) ((T*)a.y)[(size_t)n * a.O + o] = (T)r;
+        else ((float*)a.y)[(size_t)n * a.O + o] = r;
     }
     stamp(2);
 }
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) {
     // many partial rows (SE fc1 partials, pooled ASPP input): 1024 threads so that one round of loads covers them
     const int nth = a.nparts > 16 ? 1024 : 256;
-    const int opb = (nth / 64) * a.opw;
+    const int opb = (nth / 64) * 4;
     hipLaunchKernelGGL((gemv_act<T>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
 }
 template void launch_gemv<f16>(const GemvArgs&, int, hipStream_t);
