@@ -119,7 +119,10 @@ struct DgfWeights {                          // device blob layout (floats)
     float w3[4][16];  float b3[4];
     float seg_w[16];  float seg_b;
 };
-struct DgfLowArgs { const void* hid; const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast; };
+struct DgfLowArgs {
+    const void* hid; const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast;
+    const void* mlp;                        // deep refiner: 9 MFMA weight fragments (hi/lo fp16), see pack in engine.cpp
+};
 struct DgfApplyArgs {
     const void* src; const float* ab; void* fgr; void* pha;
     int H, W, h, w; float scale_y, scale_x;

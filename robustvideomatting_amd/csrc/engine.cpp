@@ -191,7 +191,7 @@ struct rvm_ctx {
     GruLayer gru[4];            // decode4, decode3, decode2, decode1
     Conv3Layer up[3];           // decode3, decode2, decode1
     Conv3Layer out0, out1;      // decode0 conv.0, conv.3
-    size_t dgf = 0;
+    size_t dgf = 0, dgf_mlp = 0;
 
     // plan
     bool planned = false;
@@ -540,6 +540,33 @@ int finalize_impl(rvm_ctx* c) {
         }
         c->dgf = c->blob_alloc(sizeof d);
         memcpy(c->blob.data() + c->dgf, &d, sizeof d);
+        c->dgf_mlp = 0;
+        if (c->refiner == RVM_REFINER_DEEP_GUIDED_FILTER) {
+            // MFMA fragments of the refiner MLP for dgf_lowres_mfma (kernels.hip): 9 fragments of 512 (hi) + 512 (lo)
+            // halves; lane (row r = lane & 15, group g = lane >> 4), element j <-> K slot 8g + j.
+            std::vector<float> fr(9 * 512, 0.f);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4;
+                for (int j = 0; j < 8; ++j) {
+                    for (int t = 0; t < 4; ++t) {
+                        const int rg = (g - t) & 3;                       // role of this lane group for tile t
+                        if (rg < 3) fr[(size_t)t * 512 + lane * 8 + j] = d.w1[r][rg * 8 + j];      // [cov|var], hid[0..7], hid[8..15]
+                        const int o = r - 4 * t;                          // last layer: real rows at 4t..4t+3
+                        if (o >= 0 && o < 4 && j < 4) fr[(size_t)(5 + t) * 512 + lane * 8 + j] = d.w3[o][4 * g + j];
+                    }
+                    if (j < 4) fr[(size_t)4 * 512 + lane * 8 + j] = d.w2[r][4 * g + j];
+                }
+            }
+            c->dgf_mlp = c->blob_alloc(9 * 1024 * sizeof(f16));
+            f16* o16 = (f16*)(c->blob.data() + c->dgf_mlp);
+            for (int f = 0; f < 9; ++f)
+                for (int e = 0; e < 512; ++e) {
+                    const float w = fr[(size_t)f * 512 + e];
+                    const f16 hi = (f16)w;
+                    o16[f * 1024 + e] = hi;
+                    o16[f * 1024 + 512 + e] = (f16)(w - (float)hi);
+                }
+        }
     }
     HIPCHK(hipSetDevice(c->device));
     if (c->wdev) { HIPCHK(hipFree(c->wdev)); c->wdev = nullptr; }
@@ -929,6 +956,7 @@ int build_plan(rvm_ctx* c) {
     {
         DgfLowArgs lo; lo.hid = hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
         lo.fast = c->refiner == RVM_REFINER_FAST_GUIDED_FILTER;
+        lo.mlp = (!lo.fast && !getenv("RVM_DGF_VALU")) ? wb + c->dgf_mlp : nullptr;
         DgfApplyArgs ap; ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
         ap.ncols = std::min(c->w, (int)std::ceil(2048.0 * ap.scale_x) + 3);

@@ -1379,9 +1379,139 @@ __global__ __launch_bounds__(256) void dgf_lowres(DgfLowArgs a) {
     *(f32x4*)o = A;
     *(f32x4*)(o + 4) = b;
 }
+// Deep refiner, MFMA form of the same arithmetic: the per-pixel MLP (24 -> 16 -> 16 -> 4) runs as nine
+// 16x16x32 f16 MFMA tiles per 16 pixels with (hi, lo) split operands (fp32-accurate, see f32s).
+// Thread (x = tid & 15, row = tid >> 4) computes the box statistics of its pixel as before; wave w owns the
+// four 16-pixel rows 4w..4w+3 (= MFMA tiles t).  For tile t the K slots of lane group g hold
+//   (g - t) mod 4 = 0: [cov, var] of pixel (x, row t)  - exactly what lane (x, g = t) has in registers,
+//                  1: hid[0..7], 2: hid[8..15] of that pixel (loaded in this layout), 3: zeros,
+// layer outputs (4 channels per lane) feed the next layer as K slots [4 channels, 4 zeros], and the
+// last layer's 4 real rows sit at rows 4t..4t+3 so A lands in lane (x, g = t) again: no cross-lane
+// traffic.  The host packs one weight fragment per (layer, t) accordingly (engine.cpp pack_dgf_mlp).
+struct HL8 { f16x8 hi, lo; };
+__device__ __forceinline__ HL8 split8(f32x4 a, f32x4 b) {
+    f16x4 h0, l0, h1, l1;
+    split4(a, h0, l0); split4(b, h1, l1);
+    HL8 r;
+    r.hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    r.lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return r;
+}
+__device__ __forceinline__ f32x4 mma_hl(f32x4 acc, const f16* wfrag, int lane, const HL8& x) {
+    const f16x8 wh = *(const f16x8*)(wfrag + lane * 8), wl = *(const f16x8*)(wfrag + 512 + lane * 8);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, x.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, x.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, x.hi, acc, 0, 0, 0);
+    return acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
+    [[maybe_unused]] Stamper stamp;
+    __shared__ f32x4 sx[18 * 18], sy[18 * 18];
+    __shared__ __attribute__((aligned(16))) f16 wl[9 * 1024];           // W1[t] x4, W2, W3[t] x4
+    const DgfWeights& wt = *a.wt;
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const T* hid = (const T*)a.hid + (size_t)n * a.h * a.w * 16;
+    const T* s0 = (const T*)a.s0 + (size_t)n * a.h * a.w * 4;
+    // MLP weight fragments: 18 KiB, 16-byte pieces
+    {
+        f32x4 wreg[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) wreg[j] = ((const f32x4*)a.mlp)[i]; }
+        for (int pp = tid; pp < 324; pp += 256) {
+            const int py = pp / 18, px = pp - py * 18;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            f32x4 xv = f32x4{0, 0, 0, 0}, yv = xv;
+            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) {
+                const size_t pix = (size_t)gy * a.w + gx;
+                xv = ld4f(s0 + pix * 4);
+                xv[3] = (xv[0] + xv[1] + xv[2]) / 3.f;
+                F8 h0 = ld8f(hid + pix * 16), h1 = ld8f(hid + pix * 16 + 8);
+                float hv[16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hv[k] = h0.lo[k]; hv[4 + k] = h0.hi[k]; hv[8 + k] = h1.lo[k]; hv[12 + k] = h1.hi[k]; }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float sacc = wt.proj_b[o];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sacc += wt.proj_w[o][k] * hv[k];
+                    yv[o] = sacc;
+                }
+            }
+            sx[pp] = xv; sy[pp] = yv;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) ((f32x4*)wl)[i] = wreg[j]; }
+    }
+    // hid slices this lane supplies to the other three tiles of its wave (issued before the barrier)
+    const int lane = tid & 63, lx = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int gx = x0 + lx;
+    f32x4 hs[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rg = (g - t) & 3;
+        const int gyt = y0 + 4 * wave + t;
+        hs[t][0] = hs[t][1] = f32x4{0, 0, 0, 0};
+        if ((rg == 1 || rg == 2) && gyt < a.h && gx < a.w) {
+            const F8 h = ld8f(hid + ((size_t)gyt * a.w + gx) * 16 + (rg - 1) * 8);
+            hs[t][0] = h.lo; hs[t][1] = h.hi;
+        }
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- box statistics of this thread's pixel (x = lx, row = 4 * wave + g)
+    const int ly = 4 * wave + g;
+    f32x4 mx = f32x4{0, 0, 0, 0}, my = mx, exy = mx, exx = mx;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int pp = (ly + t / 3) * 18 + lx + t % 3;
+        const f32x4 xv = sx[pp], yv = sy[pp];
+        f32x4 bw;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bw[c] = wt.box[c][t];
+        mx += bw * xv; my += bw * yv; exy += bw * (xv * yv); exx += bw * (xv * xv);
+    }
+    // no fma contraction here: E[xy]-E[x]E[y] cancels, keep the reference's rounding sequence
+    f32x4 cov, var;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cov[c] = __fsub_rn(exy[c], __fmul_rn(mx[c], my[c]));
+        var[c] = __fsub_rn(exx[c], __fmul_rn(mx[c], mx[c]));
+    }
+    stamp(2);
+    // ---- MLP on the MFMA, tile by tile
+    const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g);
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    f32x4 A = z4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const HL8 in = (g == t) ? split8(cov, var) : split8(hs[t][0], hs[t][1]);
+        f32x4 acc = mma_hl(z4, wl + t * 1024, lane, in);
+        acc += b1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        acc = mma_hl(z4, wl + 4 * 1024, lane, split8(acc, z4));
+        acc += b2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        acc = mma_hl(z4, wl + (5 + t) * 1024, lane, split8(acc, z4));
+        if (g == t) A = acc;
+    }
+    A += f32x4{wt.b3[0], wt.b3[1], wt.b3[2], wt.b3[3]};
+    const int gy = y0 + ly;
+    if (gy >= a.h || gx >= a.w) return;
+    const f32x4 bq = my - A * mx;
+    float* o = a.ab + (((size_t)n * a.h + gy) * a.w + gx) * 8;
+    *(f32x4*)o = A;
+    *(f32x4*)(o + 4) = bq;
+    stamp(3);
+}
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s) {
     const int tiles_y = (a.h + 15) / 16;
-    hipLaunchKernelGGL((dgf_lowres<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
+    if (!a.fast && a.mlp) hipLaunchKernelGGL((dgf_lowres_mfma<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dgf_lowres<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
 }
 template void launch_dgf_low<f16>(const DgfLowArgs&, int, hipStream_t);
 template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
