@@ -32,7 +32,8 @@ WORKLOADS = {
     "small": dict(H=288, W=512, ds=1.0, name="rvm_mobilenetv3 512x288 ds=1 (BASELINE configs[0] shape)"),
 }
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
-MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 157.3e12, "fp32": 157.3e12}   # by arithmetic type of the mode
+MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense peak of the MFMA the mode issues (f16 / f16 split / f32)
+PMC_FILES = {"hd": "profiles/r01/pmc_hd_v2.json", "4k": "profiles/r01/pmc_4k_v2.json"}   # tools/run_pmc.sh output of this command
 
 
 def frame_algorithmic_bytes(H, W, h, w, es):
@@ -163,6 +164,14 @@ def main():
                         frac=nbytes / sec / HBM_PEAK, traffic=None)
         roof.update(kernel=name, kernel_ms=avg[k], kernel_flops=flops, kernel_bytes=nbytes,
                     sum_kernel_ms=sum(avg), launches=len(info))
+        # HBM bytes of that launch from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE + WRITE_SIZE, separate passes; DESIGN.md "Measurement" has the gfx950 calibration note)
+        pmc = os.path.join(ROOT, PMC_FILES.get(a.workload, ""))
+        if a.batch == 1 and a.dtype == "fp16" and os.path.isfile(pmc):
+            for e in json.load(open(pmc)):
+                if e["name"] == name:
+                    roof["traffic"] = e["fetch_bytes_raw"] + e["write_bytes"]
+                    roof["traffic_source"] = PMC_FILES[a.workload]
         if a.dump_kernels:
             os.makedirs(os.path.dirname(os.path.abspath(a.dump_kernels)), exist_ok=True)
             with open(a.dump_kernels, "w") as f:
@@ -177,7 +186,9 @@ def main():
             "metric": "frames/sec, rvm_mobilenetv3 at HD ds=0.25 and 4K ds=0.125, 1->8 GPUs",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp16": "f32 arithmetic, f16 tensors", "fp16fast": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"fp16": "f16 (MFMA on split hi/lo f16 operands, f32 accumulate; f16 tensors)", "fp16fast": "f16", "fp32": "f32"}[a.dtype],
+            "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "mode": a.mode,
                        "parallelism": "stream-sharded, %d independent stream(s), no collective" % (world * a.batch)},
             "roofline": roof, "cpu_baseline": cpu,

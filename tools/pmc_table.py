@@ -1,0 +1,68 @@
+"""Per-launch hardware counters from rocprofv3 --pmc passes of bench.py (tools/run_pmc.sh).
+
+    python tools/pmc_table.py <dir with p1/ p2/ p3/ pass outputs> <kernels.json> [--json]
+
+HBM traffic per launch = FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  Following MI355X_MICROARCH.md (HBM): on
+gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read, so the read side is reported
+both raw and doubled (`fetch_x2`); WRITE_SIZE is exact for 16-B-per-lane stores.  MFMA utilisation =
+SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs).
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def main():
+    root, kjson = sys.argv[1], sys.argv[2]
+    as_json = "--json" in sys.argv
+    launches = json.load(open(kjson))
+    names = [k["name"] for k in launches]
+    n = len(names)
+    per = [defaultdict(list) for _ in range(n)]
+    for f in sorted(glob.glob(root + "/p*/*/*counter_collection.csv")):
+        rows = defaultdict(dict)
+        order = {}
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                kn = r["Kernel_Name"]
+                if kn.startswith("void at::") or kn.startswith("__amd_rocclr") or "at::native" in kn:
+                    continue
+                d = int(r["Dispatch_Id"])
+                rows[d][r["Counter_Name"]] = float(r["Counter_Value"])
+                order[d] = kn
+        ids = sorted(rows)
+        ids = ids[len(ids) % n:] if len(ids) % n else ids     # whole frames, counted from the end
+        for k, d in enumerate(ids):
+            for c, v in rows[d].items():
+                per[k % n][c].append(v)
+    out = []
+    for i in range(n):
+        m = {c: sum(v) / len(v) for c, v in per[i].items()}
+        e = dict(name=names[i], flops=launches[i]["flops"], bytes=launches[i]["bytes"], ms=launches[i]["ms"])
+        e["fetch_bytes_raw"] = m.get("FETCH_SIZE", 0.0) * 1024
+        e["fetch_bytes_x2"] = 2 * e["fetch_bytes_raw"]
+        e["write_bytes"] = m.get("WRITE_SIZE", 0.0) * 1024
+        gui = m.get("GRBM_GUI_ACTIVE", 0.0)
+        e["mfma_busy_cycles"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        e["mfma_util"] = e["mfma_busy_cycles"] / (gui / 8 * 1024) if gui else 0.0
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_BUSY_CU_CYCLES"):
+            e[c] = m.get(c, 0.0)
+        e["gui_active"] = gui
+        out.append(e)
+    if as_json:
+        print(json.dumps(out, indent=1))
+        return
+    print("%-20s %10s %10s %10s %10s %8s %9s %9s" % ("launch", "alg_MB", "fetch_MB", "fetchx2_MB", "write_MB", "mfma%", "insts_mfma", "lds_confl"))
+    tot = [0, 0, 0, 0]
+    for e in out:
+        print("%-20s %10.3f %10.3f %10.3f %10.3f %8.2f %9.0f %9.0f" % (
+            e["name"], e["bytes"] / 1e6, e["fetch_bytes_raw"] / 1e6, e["fetch_bytes_x2"] / 1e6, e["write_bytes"] / 1e6,
+            100 * e["mfma_util"], e["SQ_INSTS_MFMA"], e["SQ_LDS_BANK_CONFLICT"]))
+        tot[0] += e["bytes"]; tot[1] += e["fetch_bytes_raw"]; tot[2] += e["fetch_bytes_x2"]; tot[3] += e["write_bytes"]
+    print("%-20s %10.3f %10.3f %10.3f %10.3f" % ("frame total", tot[0] / 1e6, tot[1] / 1e6, tot[2] / 1e6, tot[3] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
