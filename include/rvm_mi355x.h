@@ -62,6 +62,16 @@ int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
 int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* fgr, void* pha,
                 void* const r_out[4], int seg_pass, void* hip_stream);
 
+/* Output step of the reference driver, on the device: convert_video's composition
+ * (inference.py:116,137-141: com = fgr*pha + bgr*(1-pha) with bgr = (120,255,155)/255 for video output;
+ * cat[fgr*(pha>0), pha] for png_sequence output) fused with the writers' `frames.mul(255).byte()` and
+ * NCHW->NHWC permute (inference_utils.py:44).  fgr [N,3,H,W], pha [N,1,H,W] in the given dtype
+ * (RVM_DTYPE_F32: fp32 tensors, otherwise fp16) -> out uint8 [N,H,W,C], C = 4 for RGBA else 3.
+ * Arithmetic is rounded to the tensor dtype op by op like the torch ops it replaces (bit-identical bytes). */
+enum { RVM_COMPOSE_GREEN = 0, RVM_COMPOSE_RGBA = 1, RVM_COMPOSE_ALPHA = 2, RVM_COMPOSE_FOREGROUND = 3 };
+int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_t* out, int N, int H, int W,
+                   const float bgr[3], void* hip_stream);
+
 /* Debug / test taps: copy an intermediate activation of the LAST forward to host as fp32 NCHW.
  * Names: s0 s1 s2 s3 f1 f2 f3 f4 aspp x3 x2 x1 hid ab.  Synchronises the device. */
 int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capacity, int64_t shape[4]);

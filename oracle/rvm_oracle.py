@@ -313,3 +313,21 @@ def forward(p: P, src, r1=None, r2=None, r3=None, r4=None, downsample_ratio=1.0,
     if segmentation_pass:
         return [torch.stack(outs0, 1), *rec]
     return [torch.stack(outs0, 1), torch.stack(outs1, 1), *rec]
+
+
+# ------------------------------------------------------------------ driver output step (checker)
+def compose_frames(fgr, pha, output_type="video", dtype=None):
+    """inference.py:116,137-141 on [T,3,H,W] / [T,1,H,W] tensors of the run dtype: the composition the
+    reference driver hands to its writer (green-screen video frame, or RGBA for png_sequence)."""
+    dtype = dtype or fgr.dtype
+    if output_type == "video":
+        bgr = torch.tensor([120, 255, 155], dtype=dtype).div(255).view(1, 3, 1, 1)       # :116
+        return fgr * pha + bgr * (1 - pha)                                               # :137
+    fgr = fgr * pha.gt(0)                                                                # :139
+    return torch.cat([fgr, pha], dim=-3)                                                 # :140
+
+
+def frames_to_u8(frames):
+    """inference_utils.py:42-44 (VideoWriter.write): gray -> RGB repeat, mul(255).byte(), NCHW -> NHWC.
+    to_pil_image (ImageSequenceWriter, :82) applies the same mul(255).byte() to float tensors."""
+    return frames.mul(255).byte().permute(0, 2, 3, 1).contiguous()

@@ -130,6 +130,11 @@ struct DgfApplyArgs {
 };
 struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; void* fgr; void* pha; int H, W, seg; };
 
+// ---- output composition (driver step after forward) --------------------------------------------
+enum ComposeMode { COMPOSE_GREEN = 0, COMPOSE_RGBA = 1, COMPOSE_ALPHA = 2, COMPOSE_FOREGROUND = 3 };
+struct ComposeArgs { const void* fgr; const void* pha; unsigned char* out; int H, W, mode; float bgr[3]; };
+void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s);
+
 // launchers (kernels.hip)
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);
 template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s);

@@ -1173,6 +1173,21 @@ int rvm_profile_frame(rvm_ctx* c, const void* src, const void* const r_in[4], vo
     return 0;
 }
 
+int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_t* out, int N, int H, int W,
+                   const float bgr[3], void* hip_stream) {
+    if (!pha || !out || (mode != RVM_COMPOSE_ALPHA && !fgr)) return fail("rvm_compose_u8: null buffer");
+    if (mode < 0 || mode > 3) return fail("rvm_compose_u8: bad mode");
+    if (N < 1 || H < 1 || W < 1) return fail("rvm_compose_u8: bad shape");
+    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO) return fail("rvm_compose_u8: bad dtype");
+    if (mode == RVM_COMPOSE_GREEN && !bgr) return fail("rvm_compose_u8: background colour missing");
+    ComposeArgs a; memset(&a, 0, sizeof a);
+    a.fgr = fgr; a.pha = pha; a.out = out; a.H = H; a.W = W; a.mode = mode;
+    for (int k = 0; k < 3; ++k) a.bgr[k] = bgr ? bgr[k] : 0.f;
+    launch_compose(a, N, dtype != RVM_DTYPE_F32, (hipStream_t)hip_stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
     if (!out || capacity < 2 * 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 2*512*16 values");
     unsigned int n[2] = {0, 0};

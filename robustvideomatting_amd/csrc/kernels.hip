@@ -1679,6 +1679,59 @@ template void launch_proj_out<f16>(const ProjOutArgs&, int, bool, hipStream_t);
 template void launch_proj_out<float>(const ProjOutArgs&, int, bool, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
+// Output step of the reference driver on the device (inference.py:116,137-141 and the writers'
+// `frames.mul(255).byte()` + NCHW->NHWC, inference_utils.py:44): from fgr [N,3,H,W] / pha [N,1,H,W] to
+// uint8 [N,H,W,C] frames in one pass.  Every tensor op of the reference rounds to the tensor dtype, so
+// the arithmetic below is written in that type (TIO) op by op: the bytes are identical.
+//   GREEN      com = fgr * pha + bgr * (1 - pha)            C = 3   (video composition, green screen)
+//   RGBA       cat[fgr * (pha > 0), pha]                   C = 4   (png_sequence composition)
+//   ALPHA      pha repeated to 3 channels                  C = 3   (VideoWriter grayscale -> RGB)
+//   FOREGROUND fgr                                         C = 3
+// ------------------------------------------------------------------------------------------
+template <typename TIO> __device__ __forceinline__ unsigned char to_byte(TIO v) {
+    const TIO m = v * (TIO)255.0f;                                   // .mul(255) in the tensor dtype
+    return (unsigned char)(int)(float)m;                            // .byte(): truncation (values are in [0, 255])
+}
+template <typename TIO>
+__global__ __launch_bounds__(256) void compose_u8(ComposeArgs a) {
+    [[maybe_unused]] Stamper stamp;
+    const size_t plane = (size_t)a.H * a.W;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (p >= plane) return;
+    const TIO* f = (const TIO*)a.fgr + (size_t)n * 3 * plane + p;
+    const TIO al = ((const TIO*)a.pha)[(size_t)n * plane + p];
+    const int C = a.mode == COMPOSE_RGBA ? 4 : 3;
+    unsigned char* o = a.out + ((size_t)n * plane + p) * C;
+    if (a.mode == COMPOSE_ALPHA) {
+        const unsigned char b = to_byte<TIO>(al);
+        o[0] = b; o[1] = b; o[2] = b;
+        return;
+    }
+    const TIO one = (TIO)1.0f, zero = (TIO)0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        TIO v = f[c * plane];
+        if (a.mode == COMPOSE_GREEN) {
+#pragma clang fp contract(off)                                       // no fma: the reference rounds after every op
+            const TIO t1 = v * al;                                   // each op rounds to TIO like the torch ops do
+            const TIO t2 = one - al;
+            const TIO t3 = (TIO)a.bgr[c] * t2;
+            v = t1 + t3;
+        } else if (a.mode == COMPOSE_RGBA) {
+            v = v * (al > zero ? one : zero);
+        }
+        o[c] = to_byte<TIO>(v);
+    }
+    if (a.mode == COMPOSE_RGBA) o[3] = to_byte<TIO>(al);
+}
+void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s) {
+    const dim3 grid((unsigned)(((size_t)a.H * a.W + 255) / 256), N);
+    if (io16) hipLaunchKernelGGL((compose_u8<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((compose_u8<float>), grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool on NHWC (torchvision ResNet.maxpool, reference resnet.py:25).
 // ------------------------------------------------------------------------------------------
 template <typename T>

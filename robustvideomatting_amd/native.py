@@ -19,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_state_shape", "rvm_forward",
-    "rvm_debug_tap", "rvm_debug_stamps", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -66,6 +66,8 @@ def lib():
     L.rvm_debug_tap.restype = ci
     L.rvm_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ci, ctypes.POINTER(ci)]
     L.rvm_debug_stamps.restype = ci
+    L.rvm_compose_u8.argtypes = [ci, ci, vp, vp, vp, ci, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
+    L.rvm_compose_u8.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
     L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
@@ -81,6 +83,16 @@ def lib():
     L.rvm_version.restype = ctypes.c_char_p
     _lib = L
     return L
+
+
+COMPOSE_GREEN, COMPOSE_RGBA, COMPOSE_ALPHA, COMPOSE_FOREGROUND = 0, 1, 2, 3
+
+
+def compose_u8(dtype_code, mode, fgr_ptr, pha_ptr, out_ptr, N, H, W, bgr, stream):
+    """rvm_compose_u8 on raw device pointers (see include/rvm_mi355x.h)."""
+    c3 = (ctypes.c_float * 3)(*(bgr if bgr is not None else (0.0, 0.0, 0.0)))
+    check(lib().rvm_compose_u8(dtype_code, mode, ctypes.c_void_p(fgr_ptr) if fgr_ptr else None, ctypes.c_void_p(pha_ptr),
+                               ctypes.c_void_p(out_ptr), N, H, W, c3, ctypes.c_void_p(stream)), "rvm_compose_u8")
 
 
 def debug_stamps():
