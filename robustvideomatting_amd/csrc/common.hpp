@@ -137,7 +137,6 @@ void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s);
 
 // launchers (kernels.hip)
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);
-template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s);
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s);
 template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s);
@@ -148,9 +147,6 @@ template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK);
-void dw_block_shape(int C, int* cgb, int* pyb);
-size_t dw_lds_bytes(int K, int nrows, int Wi, int es);
-template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s);
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s);
 size_t ed_lds_bytes(int K, int KS, int npxs, int es);
 int stamps_read(unsigned long long* out, unsigned int* nlaunch);   // in-kernel timeline (RVM_STAMPS builds)

@@ -760,7 +760,8 @@ int build_plan(rvm_ctx* c) {
                 const int nslice = cdiv(exp, 16);
                 auto rows_for = [&](int rb) { return std::min(Hi, (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
                 const int KS = b.has_expand ? b.expand.KS : 0;
-                auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(rows_for(rb) * Wi, 16), (int)es); };
+                auto trows_for = [&](int rb) { return (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1; };      // zero-padded tile rows
+                auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16), (int)es); };
                 int rb = Ho;
                 // split into bands while the tile does not fit ~72 KB, or while the grid is small and the
                 // halo rows recomputed by the split stay below 60 % of the image
@@ -773,20 +774,32 @@ int build_plan(rvm_ctx* c) {
                 }
                 EdArgs a; memset(&a, 0, sizeof a);
                 a.x = cur; a.Cin = curC; a.xs = curC;
-                if (b.has_expand) { a.w = wb + b.expand.w; a.KS = b.expand.KS; a.NT = b.expand.NT; a.ebias = (const float*)(wb + b.expand.bias); a.eact = b.expand.act; }
+                // Every block of the fused kernel reads the band's whole input (all Cin channels); a CU pulls
+                // only ~30-70 GB/s, so when that is more than ~160 KB per block (the 5x5 dilated layers at
+                // 1/16 scale, whose halo forbids bands) the expand runs as its own full-chip GEMM instead and
+                // the fused kernel starts from the expanded tensor (16-channel slices, no redundancy).
+                const size_t xbytes = (size_t)rows_for(rb) * Wi * curC * es;
+                bool fuse_e = b.has_expand && !(xbytes > 160 * 1024 && !getenv("RVM_ED_ALWAYS_FUSE"));
+                if (b.has_expand && !fuse_e) {
+                    T* e = abuf((size_t)B * Hi * Wi * exp);
+                    pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
+                    a.x = e; a.Cin = exp; a.xs = exp;
+                }
+                if (fuse_e) { a.w = wb + b.expand.w; a.KS = b.expand.KS; a.NT = b.expand.NT; a.ebias = (const float*)(wb + b.expand.bias); a.eact = b.expand.act; }
                 a.dw_w = (const float*)(wb + b.dw.w); a.dw_b = (const float*)(wb + b.dw.bias); a.dact = b.dw.act;
                 a.y = dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
-                a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(rows_for(rb) * Wi, 16);
+                a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16);
                 { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
-                if (a.KS > 5 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024) return fail("mbconv_ed: unsupported block shape");
+                if (a.KS > 5 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * Wi >= 65536 || (b.has_se && b.se.S > 1024))
+                    return fail("mbconv_ed: unsupported block shape");
                 const int nparts = nslice * a.nband;
                 float* hpart = nullptr;
                 if (b.has_se) {
                     hpart = fbuf((size_t)B * nparts * b.se.S);
                     a.fc1_w = (const float*)(wb + b.se.w1f); a.S = b.se.S; a.hpart = hpart;
                 }
-                const double eflops = b.has_expand ? 2.0 * B * Hi * Wi * curC * exp : 0.0;
-                add("mb" + std::to_string(i + 1) + ".expand_dw" + std::to_string(K),
+                const double eflops = fuse_e ? 2.0 * B * Hi * Wi * curC * exp : 0.0;
+                add("mb" + std::to_string(i + 1) + (fuse_e || !b.has_expand ? ".expand_dw" : ".dw") + std::to_string(K),
                     eflops + 2.0 * B * npix * exp * K * K, ((double)B * (Hi * Wi * curC + npix * exp) + (double)curC * exp) * es,
                     [=](hipStream_t st, const FrameIO&) {
                         if constexpr (std::is_same<T, float>::value) { if (split) { launch_ed<f32s>(a, B, K, st); return; } }

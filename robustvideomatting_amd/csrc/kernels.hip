@@ -336,186 +336,6 @@ template void launch_pw<float>(const PwArgs&, int, int, hipStream_t);
 template void launch_pw<f32s>(const PwArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-// Depthwise k x k conv (+folded BN, activation, optional squeeze-excite partial sums).
-// Replaces torchvision InvertedResidual's depthwise ConvBNActivation and the avg-pool half
-// of SqueezeExcitation (mobilenetv3.py:39-58).  Block = (<=32 channel groups of 8) x PY pixel
-// lanes; grid = (channel-group blocks, pixel chunks, images).  Taps are branch-free (clamped
-// address + 0/1 mask) so all k*k loads of a pixel are in flight together.  A thread keeps one
-// 8-channel group, so the SE sums reduce deterministically: registers -> LDS -> one partial
-// row per pixel chunk.
-// ------------------------------------------------------------------------------------------
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dw_conv(DwArgs a) {
-    [[maybe_unused]] Stamper stamp;
-    extern __shared__ __attribute__((aligned(16))) float red[];
-    const int cgl = threadIdx.x, CGB = blockDim.x, py = threadIdx.y, PY = blockDim.y, n = blockIdx.z;
-    const int cg = blockIdx.x * CGB + cgl;
-    const bool cvalid = cg * 8 < a.C;
-    const int c = cvalid ? cg * 8 : 0;
-    const int npix = a.Ho * a.Wo;
-    const int pbeg = blockIdx.y * a.ppb;
-    const int pend = min(pbeg + a.ppb, npix);
-    const T* xb = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.C + c;
-    T* yb = (T*)a.y + (size_t)n * npix * a.C + c;
-    const float* wb = a.w + c;
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    f32x4 ps0 = f32x4{0, 0, 0, 0}, ps1 = ps0;
-    for (int p = pbeg + py; p < pend; p += PY) {
-        const int oy = p / a.Wo, ox = p - oy * a.Wo;
-        f32x4 a0 = b0, a1 = b1;
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {                   // one tap row (K loads + weights) in flight at a time
-            const int iy = oy * a.stride - a.pad + ky * a.dil;
-            const int iyc = min(max(iy, 0), a.Hi - 1);
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int ix = ox * a.stride - a.pad + kx * a.dil;
-                const int ixc = min(max(ix, 0), a.Wi - 1);
-                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-                F8 v = ld8f(xb + ((size_t)iyc * a.Wi + ixc) * a.C);
-                const float* wp = wb + (ky * K + kx) * a.C;
-                a0 += (v.lo * m) * *(const f32x4*)wp;
-                a1 += (v.hi * m) * *(const f32x4*)(wp + 4);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a0[r] = act_f(a0[r], a.act); a1[r] = act_f(a1[r], a.act); }
-        if (cvalid) {
-            F8 o; o.lo = a0; o.hi = a1;
-            st8f(yb + (size_t)p * a.C, o);
-        }
-        ps0 += a0; ps1 += a1;
-    }
-    if (a.pool) {
-        const int RS = CGB * 8;
-        *(f32x4*)(red + py * RS + cgl * 8) = ps0;
-        *(f32x4*)(red + py * RS + cgl * 8 + 4) = ps1;
-        __syncthreads();
-        if (py == 0 && cvalid) {
-            for (int q = 1; q < PY; ++q) {
-                ps0 += *(const f32x4*)(red + q * RS + cgl * 8);
-                ps1 += *(const f32x4*)(red + q * RS + cgl * 8 + 4);
-            }
-            float* o = a.pool + ((size_t)n * a.nblk + blockIdx.y) * a.C + c;
-            *(f32x4*)o = ps0;
-            *(f32x4*)(o + 4) = ps1;
-        }
-    }
-}
-
-// LDS-tiled depthwise conv for the small pyramid levels.  A block owns 8 channels and a band of
-// output rows: it stages every input row the band needs (full width, 8 channels) and the k*k
-// weights of its channels into LDS with batched loads, then each thread produces output pixels
-// from LDS only.  At 17x30 a band is the whole image, so the squeeze-excite sum of the block's
-// channels is complete in one block (one partial row).
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dw_conv_lds(DwArgs a) {
-    [[maybe_unused]] Stamper stamp;
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
-    const int tid = threadIdx.x, n = blockIdx.z;
-    const int c = blockIdx.x * 8;
-    const int r0 = blockIdx.y * a.ppb;                                  // ppb = output rows per band here
-    const int r1 = min(r0 + a.ppb, a.Ho);
-    const int in_lo = max(r0 * a.stride - a.pad, 0);
-    const int in_hi = min((r1 - 1) * a.stride - a.pad + (K - 1) * a.dil, a.Hi - 1);
-    const int nrows = in_hi - in_lo + 1;
-    float* wl = (float*)dsm;                                            // [K*K][8]
-    float* red = wl + K * K * 8;                                        // [4 waves][8]
-    T* tile = (T*)(red + 32);                                           // [nrows][Wi][8]
-    const T* xb = (const T*)a.x + ((size_t)n * a.Hi + in_lo) * a.Wi * a.C + c;
-    // ---- stage: 2 quads per pixel, 8 items per thread per round
-    {
-        const int total = nrows * a.Wi * 2;
-        for (int it0 = tid; it0 < total; it0 += 256 * 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = min(it0 + u * 256, total - 1);
-                v[u] = ld4f(xb + (size_t)(it >> 1) * a.C + (it & 1) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = it0 + u * 256;
-                if (it < total) st4f(tile + (size_t)it * 4, v[u]);
-            }
-        }
-        for (int i = tid; i < K * K * 8; i += 256) wl[i] = a.w[(size_t)(i >> 3) * a.C + c + (i & 7)];
-    }
-    __syncthreads();
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    f32x4 ps0 = f32x4{0, 0, 0, 0}, ps1 = ps0;
-    const int npx = (r1 - r0) * a.Wo;
-    T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C + c;
-    for (int p = tid; p < npx; p += 256) {
-        const int oyl = p / a.Wo, ox = p - oyl * a.Wo;
-        const int iy0 = (r0 + oyl) * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        f32x4 a0 = b0, a1 = b1;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int iy = iy0 + ky * a.dil;
-            const int iyc = min(max(iy, in_lo), in_hi);
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int ix = ix0 + kx * a.dil;
-                const int ixc = min(max(ix, 0), a.Wi - 1);
-                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-                const F8 v = ld8f(tile + ((size_t)(iyc - in_lo) * a.Wi + ixc) * 8);
-                const float* wp = wl + (ky * K + kx) * 8;
-                a0 += (v.lo * m) * *(const f32x4*)wp;
-                a1 += (v.hi * m) * *(const f32x4*)(wp + 4);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a0[r] = act_f(a0[r], a.act); a1[r] = act_f(a1[r], a.act); }
-        F8 o; o.lo = a0; o.hi = a1;
-        st8f(yb + (size_t)p * a.C, o);
-        ps0 += a0; ps1 += a1;
-    }
-    if (a.pool) {
-        // wave reduce (fixed butterfly order), then 4 waves through LDS
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ps0[r] += __shfl_xor(ps0[r], m); ps1[r] += __shfl_xor(ps1[r], m); }
-        }
-        const int wave = tid >> 6, lane = tid & 63;
-        if (lane == 0) { *(f32x4*)(red + wave * 8) = ps0; *(f32x4*)(red + wave * 8 + 4) = ps1; }
-        __syncthreads();
-        if (tid < 8) {
-            const float sum = ((red[tid] + red[8 + tid]) + red[16 + tid]) + red[24 + tid];
-            a.pool[((size_t)n * a.nblk + blockIdx.y) * a.C + c + tid] = sum;
-        }
-    }
-}
-size_t dw_lds_bytes(int K, int nrows, int Wi, int es) { return (size_t)(K * K * 8 + 32) * 4 + (size_t)nrows * Wi * 8 * es; }
-template <typename T> void launch_dw_lds(const DwArgs& a, int N, int K, int max_rows, hipStream_t s) {
-    dim3 grid(a.C / 8, a.nblk, N);
-    const size_t lds = dw_lds_bytes(K, max_rows, a.Wi, sizeof(T));
-    if (K == 3) hipLaunchKernelGGL((dw_conv_lds<T, 3>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dw_conv_lds<T, 5>), grid, dim3(256), lds, s, a);
-}
-template void launch_dw_lds<f16>(const DwArgs&, int, int, int, hipStream_t);
-template void launch_dw_lds<float>(const DwArgs&, int, int, int, hipStream_t);
-
-void dw_block_shape(int C, int* cgb, int* pyb) {
-    const int CG = C / 8;
-    const int ncb = (CG + 31) / 32;
-    *cgb = (CG + ncb - 1) / ncb;
-    *pyb = 256 / *cgb;
-}
-template <typename T> void launch_dw(const DwArgs& a, int N, int K, hipStream_t s) {
-    int CGB, PYB;
-    dw_block_shape(a.C, &CGB, &PYB);
-    const int ncb = (a.C / 8 + CGB - 1) / CGB;
-    dim3 block(CGB, PYB), grid(ncb, a.nblk, N);
-    size_t lds = a.pool ? (size_t)PYB * CGB * 8 * sizeof(float) : 0;
-    if (K == 3) hipLaunchKernelGGL((dw_conv<T, 3>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((dw_conv<T, 5>), grid, block, lds, s, a);
-}
-template void launch_dw<f16>(const DwArgs&, int, int, hipStream_t);
-template void launch_dw<float>(const DwArgs&, int, int, hipStream_t);
-
-// ------------------------------------------------------------------------------------------
 // Fused inverted-residual front half: 1x1 expand (+BN+act) on the MFMA straight into an LDS tile,
 // depthwise k x k (+BN+act) out of that tile, and - for squeeze-excite blocks - the block's share of
 // the SE average pool pushed through fc1 (fc1 is linear before its ReLU, so per-block partial
@@ -532,6 +352,24 @@ constexpr int ED_KSMAX = 5;                                  // Cin <= 160
 size_t ed_lds_bytes(int K, int KS, int npxs, int es) {
     return (size_t)4 * npxs * 16 + (size_t)KS * 512 * es + (size_t)(K * K * 16 + 32 + 16) * 4 + 4096;
 }
+// sum over the 64 lanes of a wave, same value in every lane: DPP adds inside the rows of 16, then the four
+// row totals through readlane (fixed order)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1) {
+        const int t = sh == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)
+                    : sh == 2 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)
+                    : sh == 4 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)
+                              : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true);
+        v += __builtin_bit_cast(float, t);
+    }
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31)))
+         + (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63)));
+}
+// The LDS tile is ZERO-PADDED like the convolution's input: tile row tr <-> input row r0*stride - pad + tr,
+// tile column tc <-> input column tc - pad, so a tap is a constant offset from the output's base address
+// (no clamps, no masks in the depthwise loop).
 template <typename T, int K>
 __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     [[maybe_unused]] Stamper stamp;
@@ -540,9 +378,11 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     const int slice = blockIdx.x, band = blockIdx.y, n = blockIdx.z;
     const int c0 = slice * 16;
     const int r0 = band * a.rb, r1 = min(r0 + a.rb, a.Ho);
-    const int in_lo = max(r0 * a.stride - a.pad, 0);
-    const int in_hi = min((r1 - 1) * a.stride - a.pad + (K - 1) * a.dil, a.Hi - 1);
-    const int NPX = (in_hi - in_lo + 1) * a.Wi;
+    const int t_lo = r0 * a.stride - a.pad;                          // input row of tile row 0 (may be negative)
+    const int trows = (r1 - r0 - 1) * a.stride + (K - 1) * a.dil + 1;
+    const int in_lo = max(t_lo, 0), in_hi = min(t_lo + trows - 1, a.Hi - 1);
+    const int NPX = (in_hi - in_lo + 1) * a.Wi;                      // real input pixels of the band (contiguous)
+    const int PWt = a.Wi + 2 * a.pad;
     f32x4* ebuf = (f32x4*)smem;                                      // [4][npxs]
     T* we = (T*)(ebuf + 4 * a.npxs);                                 // [KS][512]
     float* wd = (float*)(we + (size_t)a.KS * 512);                   // [K*K][16]
@@ -551,6 +391,11 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     float* psum = be + 16;                                           // [16]
     f32x4* red = (f32x4*)(psum + 16);                                // [<= 256] per-wave-item partial sums
     const T* xb = (const T*)a.x + ((size_t)n * a.Hi + in_lo) * a.Wi * a.xs;
+    const unsigned invW = 0xFFFFFFFFu / (unsigned)a.Wi + 1u;         // px / Wi == umulhi(px, invW) for px < 2^16
+    auto tile_index = [&](int px) {                                  // flat band pixel -> padded tile index
+        const int iy = (int)__umulhi((unsigned)px, invW), ix = px - iy * a.Wi;
+        return (in_lo - t_lo + iy) * PWt + ix + a.pad;
+    };
 
     // ---- E: expand into the LDS tile.  The first m-tile's pixel loads are issued before the weights are
     //      staged so that both round trips to L2 overlap.
@@ -567,7 +412,13 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         }
     };
     if (a.w && wave < MT && !(a.dbg & 1)) load_x(wave);
-    // weights of this channel slice into LDS
+    // SE: this block's 16 columns of the fc1 rows, requested now, used after the depthwise pass
+    f32x4 w1[4];
+    if (a.hpart && tid < a.S && c0 + 16 <= a.C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w1[q] = *(const f32x4*)(a.fc1_w + (size_t)tid * a.C + c0 + q * 4);
+    }
+    // weights of this channel slice into LDS, zero the tile
     {
         f32x4 wreg[2];
         const int pieces = a.w ? a.KS * 512 * (int)sizeof(T) / 16 : 0;         // <= 5 * 128 = 640 < 1024
@@ -579,6 +430,11 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             const int c = c0 + (tid & 15);
             if (c < a.C) bdv = a.dw_b[c];
             if (a.w) bev = a.ebias[c];
+        }
+        const int tcells = trows * PWt;
+        for (int i = tid; i < 4 * tcells; i += 1024) {
+            const int q = i / tcells;
+            ebuf[q * a.npxs + (i - q * tcells)] = f32x4{0, 0, 0, 0};
         }
         if (tid < pieces) *(f32x4*)((char*)we + (size_t)tid * 16) = wreg[0];
         if (tid < K * K * 16) wd[tid] = dwv;
@@ -602,12 +458,12 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             f32x4 v = acc + *(const f32x4*)(be + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.eact);
-            if (px < NPX) ebuf[g * a.npxs + px] = v;
+            if (px < NPX) ebuf[g * a.npxs + tile_index(px)] = v;
         }
     } else {
         for (int it = tid; it < NPX * 4; it += 1024) {
             const int px = it >> 2, q = it & 3;
-            ebuf[q * a.npxs + px] = (c0 + q * 4 < a.C) ? ld4f(xb + (size_t)px * a.xs + c0 + q * 4) : f32x4{0, 0, 0, 0};
+            if (c0 + q * 4 < a.C) ebuf[q * a.npxs + tile_index(px)] = ld4f(xb + (size_t)px * a.xs + c0 + q * 4);
         }
     }
     __syncthreads();
@@ -618,39 +474,32 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     const int npo_pad = (npo + 63) & ~63;
     const int wpq = npo_pad >> 6;                                    // wave-items per channel quad
     T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C;
+    const unsigned invWo = 0xFFFFFFFFu / (unsigned)a.Wo + 1u;
+    const int rowstep = a.dil * PWt;
     for (int it = tid; it < 4 * npo_pad; it += 1024) {
         const int q = it / npo_pad, p = it - q * npo_pad;            // q is wave-uniform
         const bool valid = p < npo;
         const int pp = valid ? p : 0;
-        const int oyl = pp / a.Wo, ox = pp - oyl * a.Wo;
-        const int iy0 = (r0 + oyl) * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        const f32x4* eq = ebuf + q * a.npxs;
+        const int oyl = (int)__umulhi((unsigned)pp, invWo), ox = pp - oyl * a.Wo;
+        const f32x4* eq = ebuf + q * a.npxs + (oyl * a.stride) * PWt + ox * a.stride;
+        const float* wq = wd + q * 4;
         f32x4 acc = *(const f32x4*)(bd + q * 4);
 #pragma unroll 1
         for (int ky = 0; ky < ((a.dbg & 2) ? 0 : K); ++ky) {         // one tap row in flight at a time (registers)
-            const int iy = iy0 + ky * a.dil;
-            const int iyc = min(max(iy, in_lo), in_hi);
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int ix = ix0 + kx * a.dil;
-                const int ixc = min(max(ix, 0), a.Wi - 1);
-                const float m = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-                const f32x4 v = eq[(iyc - in_lo) * a.Wi + ixc];
-                acc += (v * m) * *(const f32x4*)(wd + (ky * K + kx) * 16 + q * 4);
-            }
+            for (int kx = 0; kx < K; ++kx)
+                acc += eq[kx * a.dil] * *(const f32x4*)(wq + (ky * K + kx) * 16);
+            eq += rowstep;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = act_f(acc[r], a.dact);
         const bool cok = c0 + q * 4 < a.C;
         if (valid && cok && !(a.dbg & 4)) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
         if (a.hpart) {
-            f32x4 s = valid ? acc : f32x4{0, 0, 0, 0};
+            f32x4 s4;
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], m);
-            }
-            if (lane == 0) red[it >> 6] = s;                         // slot = q * wpq + (p >> 6)
+            for (int r = 0; r < 4; ++r) s4[r] = wave_sum(valid ? acc[r] : 0.f);
+            if (lane == 0) red[it >> 6] = s4;                        // slot = q * wpq + (p >> 6)
         }
     }
     stamp(3);
@@ -659,26 +508,29 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         if (tid < 16) {
             const int q = tid >> 2, r = tid & 3;
             float s = 0.f;
-            for (int j = 0; j < wpq; ++j) s += red[q * wpq + j][r];
+            for (int j0 = 0; j0 < wpq; j0 += 8) {                    // 8 independent LDS reads per round, fixed order
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (j0 + j < wpq) ? red[q * wpq + min(j0 + j, wpq - 1)][r] : 0.f;
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
             psum[tid] = (c0 + tid < a.C) ? s : 0.f;
         }
         __syncthreads();
-        // fc1 partial: h[s] += sum_c W1[s][c0 + c] * psum[c]
+        // fc1 partial: h[s] = sum_c W1[s][c0 + c] * psum[c]
         const int nparts = gridDim.x * a.nband;
         float* hp = a.hpart + ((size_t)n * nparts + slice * a.nband + band) * a.S;
-        for (int sidx = tid; sidx < a.S; sidx += 1024) {
-            const float* wr = a.fc1_w + (size_t)sidx * a.C + c0;
+        if (tid < a.S) {
             float h = 0.f;
             if (c0 + 16 <= a.C) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 w4 = *(const f32x4*)(wr + q * 4);
-                    h += w4[0] * psum[q * 4] + w4[1] * psum[q * 4 + 1] + w4[2] * psum[q * 4 + 2] + w4[3] * psum[q * 4 + 3];
-                }
+                for (int q = 0; q < 4; ++q)
+                    h += w1[q][0] * psum[q * 4] + w1[q][1] * psum[q * 4 + 1] + w1[q][2] * psum[q * 4 + 2] + w1[q][3] * psum[q * 4 + 3];
             } else {
+                const float* wr = a.fc1_w + (size_t)tid * a.C + c0;
                 for (int c = 0; c0 + c < a.C; ++c) h += wr[c] * psum[c];
             }
-            hp[sidx] = h;
+            hp[tid] = h;
         }
     }
     stamp(4);
@@ -1777,10 +1629,6 @@ template <typename T> static void conv_attr_all() {
     conv_attr<T, 1, 2, 3, 2, 1>(); conv_attr<T, 1, 2, 3, 1, 2>(); conv_attr<T, 1, 2, 7, 2, 1>();
 }
 void kernels_init() {
-    (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)dw_conv_lds<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)dw_conv_lds<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
     (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
