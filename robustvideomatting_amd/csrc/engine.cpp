@@ -762,15 +762,21 @@ int build_plan(rvm_ctx* c) {
                 const int KS = b.has_expand ? b.expand.KS : 0;
                 auto trows_for = [&](int rb) { return (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1; };      // zero-padded tile rows
                 auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16), (int)es); };
+                // Rows per band: the 1024-thread blocks run one per CU, so the launch takes
+                // ceil(blocks / 256) rounds of (tile rows) work each; pick the band height that minimises
+                // rounds x tile rows with the tile inside LDS.  SE layers keep <= 64 partial rows for the
+                // squeeze-excite reduction that follows.
                 int rb = Ho;
-                // split into bands while the tile does not fit ~72 KB, or while the grid is small and the
-                // halo rows recomputed by the split stay below 60 % of the image
-                while (rb > 1) {
-                    const int nrb = cdiv(rb, 2);
-                    const bool too_big = lds_for(rb) > 72 * 1024;
-                    const bool few = nslice * cdiv(Ho, rb) * B < 128;
-                    const bool cheap = (double)rows_for(nrb) * cdiv(Ho, nrb) <= 1.6 * Hi;
-                    if (too_big || (few && cheap)) rb = nrb; else break;
+                {
+                    double best = 1e30;
+                    for (int cand = Ho; cand >= 1; cand = cand > 1 ? cdiv(cand, 2) : 0) {
+                        const int bands = cdiv(Ho, cand);
+                        if (lds_for(cand) > 150 * 1024) continue;
+                        if (b.has_se && nslice * bands > 64 && cand != Ho) continue;
+                        const double cost = (double)cdiv(nslice * bands * B, 256) * (trows_for(cand) + 2);   // + fixed per-block part
+                        if (cost < best - 1e-9) { best = cost; rb = cand; }
+                    }
+                    if (best > 1e29) return fail("mbconv_ed: tile does not fit LDS");
                 }
                 EdArgs a; memset(&a, 0, sizeof a);
                 a.x = cur; a.Cin = curC; a.xs = curC;
