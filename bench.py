@@ -78,6 +78,8 @@ def main():
                     help="fp16: fp16 tensors + fp32 arithmetic inside (parity-gated mode); fp16fast: fp16 storage + fp16 MFMA")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU")
+    ap.add_argument("--chunk", type=int, default=1,
+                    help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-kernels", default="")
     a = ap.parse_args()
@@ -105,7 +107,8 @@ def main():
     model = model.to(dev, tdt)
     model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")
-    src = synthetic.make_clip(1, wl["H"], wl["W"], seed=rank, B=a.batch)[:, 0].to(dev, tdt).contiguous()
+    clip = synthetic.make_clip(a.chunk, wl["H"], wl["W"], seed=rank, B=a.batch).to(dev, tdt).contiguous()
+    src = clip[:, 0].contiguous() if a.chunk == 1 else clip
     ds = wl["ds"]
 
     def sync_all():
@@ -126,7 +129,7 @@ def main():
             out = runner.step(src)
         sync_all()
         dt_local = time.perf_counter() - t0
-    fps, frames, dt = streams.aggregate_throughput(a.steps * a.batch, dt_local, dist, dev)
+    fps, frames, dt = streams.aggregate_throughput(a.steps * a.batch * a.chunk, dt_local, dist, dev)
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
 
     roof = None
@@ -139,8 +142,10 @@ def main():
         shapes = [ctx.state_shape(l) for l in (1, 2, 3, 4)]
         ra = [torch.zeros(s, device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last) for s in shapes]
         rb = [torch.zeros(s, device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last) for s in shapes]
-        fgr = torch.empty((a.batch, 3, wl["H"], wl["W"]), device=dev, dtype=tdt)
-        pha = torch.empty((a.batch, 1, wl["H"], wl["W"]), device=dev, dtype=tdt)
+        fgr = torch.empty((a.batch * a.chunk, 3, wl["H"], wl["W"]), device=dev, dtype=tdt)
+        pha = torch.empty((a.batch * a.chunk, 1, wl["H"], wl["W"]), device=dev, dtype=tdt)
+        if a.chunk > 1:
+            src = clip.transpose(0, 1).contiguous()             # the native call takes time-major frames
         acc = [0.0] * len(info)
         reps = 20
         for i in range(reps + 3):
@@ -167,7 +172,7 @@ def main():
         # HBM bytes of that launch from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE + WRITE_SIZE, separate passes; DESIGN.md "Measurement" has the gfx950 calibration note)
         pmc = os.path.join(ROOT, PMC_FILES.get(a.workload, ""))
-        if a.batch == 1 and a.dtype == "fp16" and os.path.isfile(pmc):
+        if a.batch == 1 and a.chunk == 1 and a.dtype == "fp16" and os.path.isfile(pmc):
             for e in json.load(open(pmc)):
                 if e["name"] == name:
                     roof["traffic"] = e["fetch_bytes_raw"] + e["write_bytes"]
@@ -189,7 +194,7 @@ def main():
             "vs_baseline": None,
             "dtype": {"fp16": "f16 (MFMA on split hi/lo f16 operands, f32 accumulate; f16 tensors)", "fp16fast": "f16", "fp32": "f32"}[a.dtype],
             "data": "synthetic",
-            "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "mode": a.mode,
+            "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "frames_per_step": a.batch * a.chunk, "chunk": a.chunk, "mode": a.mode,
                        "parallelism": "stream-sharded, %d independent stream(s), no collective" % (world * a.batch)},
             "roofline": roof, "cpu_baseline": cpu,
             "frame_roofline": {"algorithmic_bytes_per_frame": balg,

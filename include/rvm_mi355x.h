@@ -50,6 +50,14 @@ int rvm_finalize(rvm_ctx* ctx);
 /* Fix the problem shape: src is [B,3,H,W]; downsample_ratio as in forward().  Allocates the
  * activation arena (hipMalloc) - call outside any timed / captured region.  Re-planning is allowed. */
 int rvm_plan(rvm_ctx* ctx, int B, int H, int W, double downsample_ratio);
+/* The same for a chunk of a clip: src [B,T,3,H,W] (model/model.py:49-51 with 5-D input; what
+ * convert_video sends with seq_chunk = T, inference.py:127-129).  Like the reference's time-series path
+ * (decoder.py:92-105,134-143: convs on the flattened B*T frames; decoder.py:174-180: the ConvGRU loops
+ * over t), every stage outside the ConvGRUs runs once on all B*T frames and only the GRU launches are
+ * repeated per time step.  rvm_forward then takes src / fgr / pha in TIME-MAJOR order
+ * ([T][B][C][H][W], frame t of stream b at index t*B + b) and r_in / r_out as [B,C,h,w]: the state
+ * before frame 0 and after frame T-1.  rvm_plan(B, ...) == rvm_plan_seq(B, 1, ...). */
+int rvm_plan_seq(rvm_ctx* ctx, int B, int T, int H, int W, double downsample_ratio);
 /* level = 1..4 -> {B, C, h, w} of r<level> for the current plan. */
 int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
 
@@ -58,7 +66,7 @@ int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
  *   r_out[i] : receives the new state; must not alias r_in[i]
  *   seg_pass : 0 -> fgr [B,3,H,W] and pha [B,1,H,W] are written
  *              1 -> `pha` receives project_seg(hid) [B,1,h,w] (model.py:69-71), fgr is ignored
- * T>1 inputs are fed frame by frame by the caller (the recurrence is sequential, decoder.py:174-180). */
+ * After rvm_plan_seq with T>1, src / fgr / pha hold T*B frames in time-major order (see rvm_plan_seq). */
 int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* fgr, void* pha,
                 void* const r_out[4], int seg_pass, void* hip_stream);
 

@@ -126,6 +126,41 @@ def ref_blocks(variant):
 
 
 @torch.no_grad()
+def ref_decoder_chunk(variant="mobilenetv3"):
+    """SURVEY 8(f-2) pin: the reference decoder's TIME-SERIES path (decoder.py:92-105,134-143,174-180) on a
+    [B=2, T=4] chunk that starts from a non-zero state; the oracle walks the same chunk frame by frame."""
+    dec_m = _load("decoder")
+    v = spec.VARIANTS[variant]
+    p = synthetic.make_params(variant, "deep_guided_filter", seed=4)
+    g = torch.Generator().manual_seed(21)
+    B, T, h, w = 2, 4, 22, 38                       # pyramid 11x19, 6x10, 3x5, 2x3
+    sizes = spec.pyramid_sizes(h, w)
+    feat = v["feat"]
+    dec = dec_m.RecurrentDecoder(feat, v["dec"]).eval()
+    dec.load_state_dict(_sub(p, "decoder."))
+    s0 = torch.rand(B, T, 3, h, w, generator=g)
+    fs = [torch.randn(B, T, feat[i], *sizes[i], generator=g) * 0.7 for i in range(4)]
+    fs[3] = fs[3].abs()
+    rc = spec.state_channels(variant)
+    r0 = [torch.tanh(torch.randn(B, rc[i], *sizes[i], generator=g)) for i in range(4)]
+    o_ref = dec(s0, *fs, *r0)
+    rec = list(r0)
+    worst = 0.0
+    for t in range(T):
+        o = O.decoder(p, s0[:, t], *[f[:, t] for f in fs], *rec)
+        rec = list(o[1:])
+        worst = max(worst, (o[0] - o_ref[0][:, t]).abs().max().item())
+    for a, b in zip(rec, o_ref[1:]):
+        worst = max(worst, (a - b).abs().max().item())
+    print("decoder    chunk [B=2,T=4] reference time-series path vs oracle frame by frame: %.3g" % worst)
+    assert worst < 1e-5
+    fix = dict(s0=s0, f1=fs[0], f2=fs[1], f3=fs[2], f4=fs[3], r1_in=r0[0], r2_in=r0[1], r3_in=r0[2], r4_in=r0[3],
+               hid=o_ref[0], r1=o_ref[1], r2=o_ref[2], r3=o_ref[3], r4=o_ref[4])
+    np.savez_compressed(os.path.join(OUT, "ref_decoder_chunk_%s.npz" % variant),
+                        **{k: v_.numpy().astype(np.float32) for k, v_ in fix.items()})
+
+
+@torch.no_grad()
 def e2e(variant, refiner, tag, H, W, ds, T, seed):
     p = synthetic.make_params(variant, refiner, seed=seed)
     clip = synthetic.make_clip(T, H, W, seed=seed)
@@ -150,8 +185,12 @@ def e2e(variant, refiner, tag, H, W, ds, T, seed):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--chunk-only" in sys.argv:
+        ref_decoder_chunk()
+        sys.exit(0)
     ref_blocks("mobilenetv3")
     ref_blocks("resnet50")
+    ref_decoder_chunk()
     e2e("mobilenetv3", "deep_guided_filter", "ds025", 122, 218, 0.25, 4, 5)
     e2e("mobilenetv3", "deep_guided_filter", "ds1", 36, 62, 1.0, 4, 6)
     e2e("mobilenetv3", "fast_guided_filter", "fast", 122, 218, 0.25, 2, 7)

@@ -94,6 +94,7 @@ struct ConvArgs {
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
     void* hout;                             // GRU new state [N][H][W][hC]
+    void* hout2;                            // optional second copy of it (last step of a chunk: the caller's r_out)
     int state16;                            // hprev / hout are fp16 although the kernel computes in fp32
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };

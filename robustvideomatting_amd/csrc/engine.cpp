@@ -195,7 +195,7 @@ struct rvm_ctx {
 
     // plan
     bool planned = false;
-    int B = 0, H = 0, W = 0, h = 0, w = 0;
+    int B = 0, T = 1, H = 0, W = 0, h = 0, w = 0;    // B streams x T frames of each (T > 1: a chunk of a clip)
     double ds = 1;
     int lh[5], lw[5];
     char* arena = nullptr;
@@ -624,7 +624,10 @@ int build_plan(rvm_ctx* c) {
     c->launches.clear();
     c->taps.clear();
     c->arena_used = 0;
-    const int B = c->B;
+    // A chunk of T frames per stream (decoder.py:92-105,174-180): every stage outside the ConvGRUs runs on all
+    // T*Bs frames at once (frame t of stream b is sample t*Bs + b); the GRUs step through t on Bs samples.
+    const int Bs = c->B, TT = c->T;
+    const int B = Bs * TT;
     const bool split = c->split;
     const size_t es = sizeof(T);
     const int io16 = c->dtype == RVM_DTYPE_F16IO ? 1 : 0;   // fp16 tensors at the boundary, fp32 inside
@@ -670,7 +673,8 @@ int build_plan(rvm_ctx* c) {
 
     // KxK conv launcher: (Ho, Wo) output, (Hi, Wi) input of the direct sources
     auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Ho, int Wo, int Hi, int Wi, int epi,
-                     std::function<void(ConvArgs&, const FrameIO&)> fill) -> int {
+                     std::function<void(ConvArgs&, const FrameIO&)> fill, int nb = 0) -> int {
+        const int B = nb ? nb : Bs * TT;                    // samples of this launch (a GRU step: Bs)
         ConvArgs a; memset(&a, 0, sizeof a);
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
         a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
@@ -908,19 +912,33 @@ int build_plan(rvm_ctx* c) {
 
     // ---- recurrent decoder (decoder.py:17-27)
     // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
+    const size_t ses = io16 ? 2 : es;               // element size of a state tensor
+    char* hseq[4] = {nullptr, nullptr, nullptr, nullptr};   // T > 1: the T outputs of a level's GRU, [T][Bs][H][W][C]
     auto gru = [&](const std::string& name, const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
         const int C = G.C;
-        T* rh = abuf((size_t)B * Hh * Ww * C);
-        float* z = fbuf((size_t)B * Hh * Ww * C);
-        if (conv3(name + ".ih", G.ih, Hh, Ww, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
-                a.nsrc = 0;
-                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{io.r_in[ridx], C, C, 0, 0, 0, io16}; a.nsrc = 2;
-                a.hprev = io.r_in[ridx]; a.hC = C; a.rh = rh; a.z = z; a.state16 = io16;
-            })) return 1;
-        if (conv3(name + ".hh", G.hh, Hh, Ww, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
-                a.src[0] = ConvSrc{xb, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0, 0}; a.nsrc = 2;
-                a.hprev = io.r_in[ridx]; a.hC = C; a.z = z; a.hout = io.r_out[ridx]; a.state16 = io16;
-            })) return 1;
+        const size_t per = (size_t)Bs * Hh * Ww;    // pixels of one time step
+        T* rh = abuf(per * C);
+        float* z = fbuf(per * C);
+        char* hs = TT > 1 ? (char*)c->arena_alloc((size_t)TT * per * C * ses) : nullptr;
+        hseq[ridx] = hs;
+        for (int t = 0; t < TT; ++t) {
+            const std::string nm = TT > 1 ? name + "[" + std::to_string(t) + "]" : name;
+            const T* xt = xb + (size_t)t * per * xs;
+            const void* hp = t ? hs + (size_t)(t - 1) * per * C * ses : nullptr;      // nullptr: the caller's r_in
+            void* ho = hs ? hs + (size_t)t * per * C * ses : nullptr;                 // nullptr: the caller's r_out
+            const bool last = t == TT - 1;
+            if (conv3(nm + ".ih", G.ih, Hh, Ww, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
+                    const void* h = t ? hp : io.r_in[ridx];
+                    a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{h, C, C, 0, 0, 0, io16}; a.nsrc = 2;
+                    a.hprev = h; a.hC = C; a.rh = rh; a.z = z; a.state16 = io16;
+                }, Bs)) return 1;
+            if (conv3(nm + ".hh", G.hh, Hh, Ww, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
+                    a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0, 0}; a.nsrc = 2;
+                    a.hprev = t ? hp : io.r_in[ridx]; a.hC = C; a.z = z; a.state16 = io16;
+                    a.hout = ho ? ho : io.r_out[ridx];
+                    a.hout2 = (ho && last) ? io.r_out[ridx] : nullptr;                 // the state handed back
+                }, Bs)) return 1;
+        }
         return 0;
     };
         // decode4 (BottleneckBlock, decoder.py:63-67): a = aspp[:, :AC/2], b = aspp[:, AC/2:]
@@ -937,9 +955,10 @@ int build_plan(rvm_ctx* c) {
         const T* sl = s[l];
         const int Hs = lh[l + 1], Ws = lw[l + 1];
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
+        const char* hs_ = hseq[hidx];
         if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
-                a.src[1] = ConvSrc{io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, io16};
                 a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0, 0};
                 a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 4; a.y = X; a.ys = Cout;
@@ -956,9 +975,10 @@ int build_plan(rvm_ctx* c) {
         const T* xa_ = xa; const int xaC_ = xaC, xaS_ = xaS;
         const T* s0 = s[0];
         const int Hs = lh[1], Ws = lw[1];
+        const char* hs_ = hseq[0];
         if (conv3("decode0.conv0", c->out0, c->h, c->w, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
-                a.src[1] = ConvSrc{io.r_out[0], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[0], xaC_, xaC_, 1, Hs, Ws, io16};
                 a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
@@ -1006,11 +1026,12 @@ int build_plan(rvm_ctx* c) {
     return 0;
 }
 
-int plan_impl(rvm_ctx* c, int B, int H, int W, double ds) {
+int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (!c->finalized) return fail("rvm_plan: call rvm_finalize first");
-    if (B < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
+    if (B < 1 || T < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
+    if ((int64_t)B * T > 65535) return fail("rvm_plan: B*T exceeds the grid limit (65535)");
     if (!(ds > 0.0 && ds <= 1.0)) return fail("rvm_plan: downsample_ratio must be in (0, 1]");
-    c->B = B; c->H = H; c->W = W; c->ds = ds;
+    c->B = B; c->T = T; c->H = H; c->W = W; c->ds = ds;
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
     if (c->h < 1 || c->w < 1) return fail("rvm_plan: downsampled frame is empty");
@@ -1108,7 +1129,12 @@ int rvm_finalize(rvm_ctx* c) {
 
 int rvm_plan(rvm_ctx* c, int B, int H, int W, double ds) {
     if (!c) return fail("rvm_plan: null ctx");
-    return plan_impl(c, B, H, W, ds);
+    return plan_impl(c, B, 1, H, W, ds);
+}
+
+int rvm_plan_seq(rvm_ctx* c, int B, int T, int H, int W, double ds) {
+    if (!c) return fail("rvm_plan_seq: null ctx");
+    return plan_impl(c, B, T, H, W, ds);
 }
 
 int rvm_state_shape(const rvm_ctx* c, int level, int64_t shape[4]) {

@@ -948,6 +948,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
                 st4x(a.hout, pix * a.hC + c, sizeof(T) == 2 || a.state16, cv);
+                if (a.hout2) st4x(a.hout2, pix * a.hC + c, sizeof(T) == 2 || a.state16, cv);
             }
         }
     }

@@ -92,6 +92,7 @@ class MattingNetwork(nn.Module):
         self._graph = False
         self.fp16_arithmetic = "fp32"   # half() module: "fp32" = fp16 tensors, fp32 math inside (meets 2e-3);
         #                                 "fp16" = fp16 storage + fp16 MFMA inside (fastest, fp16 accuracy)
+        self.chunk_batching = True  # [B,T,...] input: one native call per chunk (rvm_plan_seq) instead of T calls
         self._ring = {}             # plan key -> ring of static output/state buffers (graph mode)
         self._ring_pos = 0
 
@@ -210,7 +211,8 @@ class MattingNetwork(nn.Module):
             B, T = src.shape[0], 1
             frames = src.unsqueeze(0)
         H, W = src.shape[-2:]
-        ctx.plan(B, H, W, ds)
+        chunk = five and T > 1 and self.chunk_batching
+        ctx.plan(B, H, W, ds, T if chunk else 1)
         shapes = [ctx.state_shape(l) for l in (1, 2, 3, 4)]
         dev, dt = src.device, src.dtype
 
@@ -232,6 +234,8 @@ class MattingNetwork(nn.Module):
             rec[i] = r.contiguous(memory_format=torch.channels_last)
 
         h0, w0 = spec.lowres_size(H, W, ds)
+        if chunk:
+            return self._run_chunk(ctx, src, rec, shapes, B, T, H, W, h0, w0, seg)
         oshape0 = (B, 1, h0, w0) if seg else (B, 3, H, W)
         oshape1 = None if seg else (B, 1, H, W)
         out0 = torch.empty((T,) + oshape0, device=dev, dtype=dt)
@@ -267,6 +271,32 @@ class MattingNetwork(nn.Module):
         else:
             outs = [out0[0]] if seg else [out0[0], out1[0]]
         return [*outs, *rec]
+
+    def _run_chunk(self, ctx, src, rec, shapes, B, T, H, W, h0, w0, seg):
+        """[B,T,3,H,W] in one native call: like the reference's time-series path (decoder.py:92-105,174-180)
+        every stage outside the ConvGRUs runs on all B*T frames at once; the native side wants time-major frames."""
+        dev, dt = src.device, src.dtype
+        tb = src.transpose(0, 1)                    # [T,B,3,H,W]; already contiguous when B == 1
+        if not tb.is_contiguous():
+            tb = tb.contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rin = [r.data_ptr() if r is not None else 0 for r in rec]
+        if self._graph and not seg:
+            ring = self._static_ring(ctx, shapes, (T * B, 3, H, W), (T * B, 1, H, W), dev, dt)
+            slot = ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % len(ring)
+            new, o0, o1 = slot["r"], slot["fgr"], slot["pha"]
+        else:
+            new = [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
+            o0 = torch.empty((T * B, 1, h0, w0) if seg else (T * B, 3, H, W), device=dev, dtype=dt)
+            o1 = None if seg else torch.empty((T * B, 1, H, W), device=dev, dtype=dt)
+        if seg:
+            ctx.forward(tb.data_ptr(), rin, 0, o0.data_ptr(), [n.data_ptr() for n in new], True, stream)
+            outs = [o0.view(T, B, 1, h0, w0).transpose(0, 1)]
+        else:
+            ctx.forward(tb.data_ptr(), rin, o0.data_ptr(), o1.data_ptr(), [n.data_ptr() for n in new], False, stream)
+            outs = [o0.view(T, B, 3, H, W).transpose(0, 1), o1.view(T, B, 1, H, W).transpose(0, 1)]
+        return [*outs, *new]
 
     def _static_ring(self, ctx, shapes, fshape, pshape, dev, dt):
         key = (ctx.plan_key, dev, dt)

@@ -18,7 +18,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 # every symbol include/rvm_mi355x.h declares
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
-    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_state_shape", "rvm_forward",
+    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward",
     "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
@@ -58,6 +58,8 @@ def lib():
     L.rvm_finalize.restype = ci
     L.rvm_plan.argtypes = [vp, ci, ci, ci, ctypes.c_double]
     L.rvm_plan.restype = ci
+    L.rvm_plan_seq.argtypes = [vp, ci, ci, ci, ci, ctypes.c_double]
+    L.rvm_plan_seq.restype = ci
     L.rvm_state_shape.argtypes = [vp, ci, i64p]
     L.rvm_state_shape.restype = ci
     L.rvm_forward.argtypes = [vp, vp, cpp, vp, vp, cpp, ci, vp]
@@ -150,10 +152,11 @@ class Context:
         check(lib().rvm_finalize(self._h), "rvm_finalize")
         self.plan_key = None
 
-    def plan(self, B, H, W, ds):
-        key = (B, H, W, float(ds))
+    def plan(self, B, H, W, ds, T=1):
+        """T > 1: a chunk of T frames per stream in one call (rvm_plan_seq; tensors time-major)."""
+        key = (B, H, W, float(ds), T)
         if key != self.plan_key:
-            check(lib().rvm_plan(self._h, B, H, W, float(ds)), "rvm_plan")
+            check(lib().rvm_plan_seq(self._h, B, T, H, W, float(ds)), "rvm_plan_seq")
             self.plan_key = key
 
     def state_shape(self, level):

@@ -27,11 +27,12 @@ class StreamRunner:
         self.frames_done = 0
 
     def step(self, src):
-        """src: [len(stream_ids), 3, H, W] - the next frame of every owned stream."""
+        """src: [len(stream_ids), 3, H, W] - the next frame of every owned stream, or
+        [len(stream_ids), T, 3, H, W] - their next T frames (one chunked call)."""
         assert src.shape[0] == len(self.stream_ids)
         out = self.model(src, None, *self.rec, self.ds)
         self.rec = out[2:]
-        self.frames_done += src.shape[0]
+        self.frames_done += src.shape[0] * (src.shape[1] if src.ndim == 5 else 1)
         return out[0], out[1]
 
 

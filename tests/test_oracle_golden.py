@@ -46,6 +46,22 @@ def test_oracle_matches_reference_blocks(variant):
     assert (b[0] - _t(g["fgf_fgr"])).abs().max() < 2e-5 and (b[1] - _t(g["fgf_pha"])).abs().max() < 2e-5
 
 
+def test_oracle_matches_reference_time_series_decoder():
+    """ref_decoder_chunk_*.npz: the reference decoder's 5-D (time-series) path on a [B=2,T=4] chunk from a
+    non-zero state (decoder.py:92-105,174-180); the oracle walks it frame by frame."""
+    g = np.load(os.path.join(GOLD, "ref_decoder_chunk_mobilenetv3.npz"))
+    p = synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=4)
+    s0, f1, f2, f3, f4 = (_t(g[k]) for k in ("s0", "f1", "f2", "f3", "f4"))
+    rec = [_t(g["r%d_in" % i]) for i in (1, 2, 3, 4)]
+    assert s0.shape[:2] == (2, 4)
+    for t in range(s0.shape[1]):
+        out = O.decoder(p, s0[:, t], f1[:, t], f2[:, t], f3[:, t], f4[:, t], *rec)
+        rec = list(out[1:])
+        assert (out[0] - _t(g["hid"])[:, t]).abs().max() < 1e-5
+    for i in range(4):
+        assert (rec[i] - _t(g["r%d" % (i + 1)])).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast", "resnet50_ds025"])
 def test_e2e_fixture_frozen(name):
     """End-to-end vectors: the oracle reproduces what was committed (guards accidental edits)."""
