@@ -206,6 +206,9 @@ struct rvm_ctx {
     };
     std::vector<Launch> launches;
     std::map<std::string, Tap> taps;
+    // plan-time tile selection by measurement (B*T > 1): launch key -> index into that launch's candidate list
+    std::map<std::string, int> tuned;
+    std::vector<std::pair<std::string, int>> tunable;   // (key, number of candidates), filled by build_plan
 
     // graph mode
     bool graph_mode = false;
@@ -619,11 +622,26 @@ template <typename T> void launch_conv3_m(const ConvArgs& a, int N, int MW, int 
     launch_conv3<T>(a, N, MW, NW, geo, s);
 }
 
+// a launch repeated per time step ("decode3.gru[5].ih") shares one tuning entry ("decode3.gru.ih")
+std::string tune_key(const std::string& name) {
+    const size_t l = name.find('['), r = name.find(']');
+    return (l == std::string::npos || r == std::string::npos) ? name : name.substr(0, l) + name.substr(r + 1);
+}
+
 template <typename T>
 int build_plan(rvm_ctx* c) {
     c->launches.clear();
     c->taps.clear();
+    c->tunable.clear();
     c->arena_used = 0;
+    auto tune_pick = [&](const std::string& name, int ncand, int model_choice) {
+        const std::string key = tune_key(name);
+        bool seen = false;
+        for (auto& t : c->tunable) seen |= t.first == key;
+        if (!seen) c->tunable.push_back({key, ncand});
+        auto it = c->tuned.find(key);
+        return (it != c->tuned.end() && it->second >= 0 && it->second < ncand) ? it->second : model_choice;
+    };
     // A chunk of T frames per stream (decoder.py:92-105,174-180): every stage outside the ConvGRUs runs on all
     // T*Bs frames at once (frame t of stream b is sample t*Bs + b); the GRUs step through t on Bs samples.
     const int Bs = c->B, TT = c->T;
@@ -665,7 +683,7 @@ int build_plan(rvm_ctx* c) {
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
-        const int cfg = pick_pw_cfg(a.MT, a.NT, a.KS, B);
+        const int cfg = tune_pick(name, 7, pick_pw_cfg(a.MT, a.NT, a.KS, B));
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
             [=](hipStream_t st, const FrameIO&) { launch_pw_m<T>(a, B, cfg, st, split); });
@@ -689,6 +707,7 @@ int build_plan(rvm_ctx* c) {
             // pick the (MW, NW) tile that minimises rounds-of-blocks x work-per-block; a round is
             // 256 CUs x the blocks whose LDS fits a CU together (ties: the larger tile, less halo)
             const int cand[5][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+            int valid[5], nvalid = 0, model = -1;
             double best = 1e30;
             for (int k = 0; k < 5; ++k) {
                 const int m = cand[k][0], nw = cand[k][1];
@@ -698,9 +717,12 @@ int build_plan(rvm_ctx* c) {
                 const int occ = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
                 const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
                 const double cost = (double)cdiv(blocks, 256 * occ) * m * nw;
-                if (cost < best - 1e-9) { best = cost; MW = m; NW = nw; }
+                if (cost < best - 1e-9) { best = cost; model = nvalid; }
+                valid[nvalid++] = k;
             }
-            if (best > 1e29) return fail("conv: input patch does not fit LDS");
+            if (nvalid == 0) return fail("conv: input patch does not fit LDS");
+            const int pick = valid[tune_pick(name, nvalid, model)];
+            MW = cand[pick][0]; NW = cand[pick][1];
         } else {
             NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
             if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
@@ -1026,6 +1048,65 @@ int build_plan(rvm_ctx* c) {
     return 0;
 }
 
+// Tile shapes by measurement.  With many frames per call (B*T > 1) a launch has blocks to spare and the
+// latency model build_plan uses for one frame (rounds of blocks x work per block) no longer ranks the
+// tiles; here every candidate of every GEMM / conv launch is timed on the device (hipEvents, a few
+// repetitions on dummy states) and the fastest kept.  Runs inside rvm_plan, never on the frame path.
+int autotune(rvm_ctx* c) {
+    auto rebuild = [&]() { return c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c); };
+    const size_t ses = c->dtype == RVM_DTYPE_F32 ? 4 : 2;
+    const int ch[4] = {c->dec[2] / 2, c->dec[1] / 2, c->dec[0] / 2, c->feat[3] / 2};
+    FrameIO io; memset(&io, 0, sizeof io);
+    void* bufs[8] = {nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (st) (void)hipStreamDestroy(st);
+    };
+#define TUNECHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(std::string("autotune: ") + hipGetErrorString(e_)); } } while (0)
+    for (int l = 0; l < 4; ++l) {
+        const size_t bytes = (size_t)c->B * ch[l] * c->lh[l + 1] * c->lw[l + 1] * ses;
+        TUNECHK(hipMalloc(&bufs[l], bytes)); TUNECHK(hipMemset(bufs[l], 0, bytes));
+        TUNECHK(hipMalloc(&bufs[4 + l], bytes)); TUNECHK(hipMemset(bufs[4 + l], 0, bytes));
+        io.r_in[l] = bufs[l]; io.r_out[l] = bufs[4 + l];
+    }
+    TUNECHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    TUNECHK(hipEventCreate(&e0)); TUNECHK(hipEventCreate(&e1));
+    const auto tunable = c->tunable;                      // build_plan refills the list
+    const bool verbose = getenv("RVM_VERBOSE") != nullptr;
+    for (const auto& t : tunable) {
+        if (t.second < 2) continue;
+        int idx = -1;
+        for (size_t i = 0; i < c->launches.size() && idx < 0; ++i)
+            if (tune_key(c->launches[i].name) == t.first) idx = (int)i;
+        if (idx < 0) continue;
+        float best = 1e30f; int bestk = 0;
+        for (int k = 0; k < t.second; ++k) {
+            c->tuned[t.first] = k;
+            if ((rc = rebuild())) { cleanup(); return rc; }
+            const int warm = 2, reps = 6;
+            for (int r = 0; r < warm; ++r) c->launches[idx].fn(st, io);
+            TUNECHK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) c->launches[idx].fn(st, io);
+            TUNECHK(hipEventRecord(e1, st));
+            TUNECHK(hipStreamSynchronize(st));
+            TUNECHK(hipGetLastError());
+            float ms = 0.f;
+            TUNECHK(hipEventElapsedTime(&ms, e0, e1));
+            if (verbose) fprintf(stderr, "[rvm tune] %-20s cand %d  %.2f us\n", t.first.c_str(), k, ms / reps * 1e3f);
+            if (ms < best) { best = ms; bestk = k; }
+        }
+        c->tuned[t.first] = bestk;
+    }
+#undef TUNECHK
+    cleanup();
+    return rebuild();
+}
+
 int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (!c->finalized) return fail("rvm_plan: call rvm_finalize first");
     if (B < 1 || T < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
@@ -1041,6 +1122,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     c->drop_graphs();
     if (c->arena) { HIPCHK(hipFree(c->arena)); c->arena = nullptr; }
     c->planned = false;
+    c->tuned.clear();
     // sizing pass (arena == nullptr), then the real pass
     int rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
     if (rc) return rc;
@@ -1049,6 +1131,11 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     HIPCHK(hipMemset(c->arena, 0, c->arena_bytes));
     rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
     if (rc) return rc;
+    {
+        const char* e = getenv("RVM_AUTOTUNE");           // "0": never, "1": also for a single frame
+        const bool tune = e ? atoi(e) != 0 && ((int64_t)B * T > 1 || atoi(e) == 1) : (int64_t)B * T > 1;
+        if (tune && (rc = autotune(c))) return rc;
+    }
     c->planned = true;
     return 0;
 }
