@@ -208,7 +208,8 @@ struct rvm_ctx {
     std::map<std::string, Tap> taps;
     // plan-time tile selection by measurement (B*T > 1): launch key -> index into that launch's candidate list
     std::map<std::string, int> tuned;
-    std::vector<std::pair<std::string, int>> tunable;   // (key, number of candidates), filled by build_plan
+    struct Tunable { std::string key; int ncand, model; };
+    std::vector<Tunable> tunable;                       // filled by build_plan: candidates and the model's choice
 
     // graph mode
     bool graph_mode = false;
@@ -586,8 +587,10 @@ int finalize_impl(rvm_ctx* c) {
 // schedule
 // ---------------------------------------------------------------------------------------------
 int pick_pw_cfg(int MT, int NT, int KS, int N) {
+    // one n-tile (mobilenetv3 block 1): bandwidth-bound, most blocks win (config 1 runs 2 of its 4 waves)
+    if (NT == 1 && KS == 1) return 1;
     // Long K on few tiles (the 1/16-scale project / ASPP GEMMs): split K over the block's 4 waves.
-    if (KS >= 8) {
+    if (KS >= 6) {
         const int sm[3] = {2, 1, 1}, sn[3] = {2, 2, 1};      // configs 4, 5, 6
         for (int k = 0; k < 3; ++k) {
             const int blocks = cdiv(MT, sm[k]) * cdiv(NT, sn[k]) * N;
@@ -606,7 +609,7 @@ int pick_pw_cfg(int MT, int NT, int KS, int N) {
         const int cfg = pref[k];
         if (bn[cfg] > 1 && cdiv(NT, bn[cfg]) * bn[cfg] >= 2 * NT) continue;   // more than half the tile idle
         const int blocks = cdiv(MT, bm[cfg]) * cdiv(NT, bn[cfg]) * N;
-        if (blocks >= 256) return cfg;
+        if (blocks >= 200) return cfg;
         if (blocks > best_blocks) { best_blocks = blocks; best = cfg; }
     }
     return best;
@@ -637,8 +640,8 @@ int build_plan(rvm_ctx* c) {
     auto tune_pick = [&](const std::string& name, int ncand, int model_choice) {
         const std::string key = tune_key(name);
         bool seen = false;
-        for (auto& t : c->tunable) seen |= t.first == key;
-        if (!seen) c->tunable.push_back({key, ncand});
+        for (auto& t : c->tunable) seen |= t.key == key;
+        if (!seen) c->tunable.push_back({key, ncand, model_choice});
         auto it = c->tuned.find(key);
         return (it != c->tuned.end() && it->second >= 0 && it->second < ncand) ? it->second : model_choice;
     };
@@ -704,8 +707,7 @@ int build_plan(rvm_ctx* c) {
         int MW = 1;
         const int geo = L.geo;
         if (geo == 0 && L.nchunks == 1) {
-            // pick the (MW, NW) tile that minimises rounds-of-blocks x work-per-block; a round is
-            // 256 CUs x the blocks whose LDS fits a CU together (ties: the larger tile, less halo)
+            // pick the (MW, NW) tile that minimises blocks-per-CU x time-per-block (ties: the larger tile, less halo)
             const int cand[5][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
             int valid[5], nvalid = 0, model = -1;
             double best = 1e30;
@@ -714,9 +716,11 @@ int build_plan(rvm_ctx* c) {
                 if (epi == EPI_GRU_IH && nw != 2) continue;
                 const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC, SK0);
                 if (lds > 150 * 1024) continue;
-                const int occ = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+                // measured on the HD frame (every candidate of the 13 decoder convs timed alone): a block takes about
+                // 2.7 us + 0.128 us per (K step x 16x16 output tile), and the blocks that share a CU take turns
+                // (they are bound by what one CU can pull from L2), so the launch costs that times the blocks per CU
                 const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
-                const double cost = (double)cdiv(blocks, 256 * occ) * m * nw;
+                const double cost = (double)cdiv(blocks, 256) * (2.7 + 0.128 * L.KS * m * nw);
                 if (cost < best - 1e-9) { best = cost; model = nvalid; }
                 valid[nvalid++] = k;
             }
@@ -1079,14 +1083,14 @@ int autotune(rvm_ctx* c) {
     const auto tunable = c->tunable;                      // build_plan refills the list
     const bool verbose = getenv("RVM_VERBOSE") != nullptr;
     for (const auto& t : tunable) {
-        if (t.second < 2) continue;
+        if (t.ncand < 2) continue;
         int idx = -1;
         for (size_t i = 0; i < c->launches.size() && idx < 0; ++i)
-            if (tune_key(c->launches[i].name) == t.first) idx = (int)i;
+            if (tune_key(c->launches[i].name) == t.key) idx = (int)i;
         if (idx < 0) continue;
         float best = 1e30f; int bestk = 0;
-        for (int k = 0; k < t.second; ++k) {
-            c->tuned[t.first] = k;
+        for (int k = 0; k < t.ncand; ++k) {
+            c->tuned[t.key] = k;
             if ((rc = rebuild())) { cleanup(); return rc; }
             const int warm = 2, reps = 6;
             for (int r = 0; r < warm; ++r) c->launches[idx].fn(st, io);
@@ -1097,10 +1101,10 @@ int autotune(rvm_ctx* c) {
             TUNECHK(hipGetLastError());
             float ms = 0.f;
             TUNECHK(hipEventElapsedTime(&ms, e0, e1));
-            if (verbose) fprintf(stderr, "[rvm tune] %-20s cand %d  %.2f us\n", t.first.c_str(), k, ms / reps * 1e3f);
+            if (verbose) fprintf(stderr, "[rvm tune] %-20s cand %d  %.2f us%s\n", t.key.c_str(), k, ms / reps * 1e3f, k == t.model ? "  (model)" : "");
             if (ms < best) { best = ms; bestk = k; }
         }
-        c->tuned[t.first] = bestk;
+        c->tuned[t.key] = bestk;
     }
 #undef TUNECHK
     cleanup();

@@ -559,7 +559,9 @@ template <int N> __device__ __forceinline__ float row_shr_add(float v) {
 // 4-element chunks sub, sub+16, ... of the weight row (coalesced 256 B per row and round).  The weight
 // chunks and the bias are requested before the input vector is reduced, so the two global round trips
 // overlap; the dot products finish with 4 DPP adds.
-template <typename T>
+// TCH = 4-element chunks of a weight row per lane: 4 covers rows of up to 256 inputs (every SE layer), 16 up to 1024
+// in registers (longer rows continue from memory).
+template <typename T, int TCH>
 __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -570,9 +572,9 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     const bool ov = o < a.O;
     const int nchunk = a.I >> 2;                                     // I % 4 == 0 (host-checked)
     const T* wrow = (const T*)a.w + (size_t)(ov ? o : 0) * a.I;
-    f32x4 w[16];
+    f32x4 w[TCH];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < TCH; ++t) {
         const int c = sub + 16 * t;
         w[t] = ld4f(wrow + 4 * min(c, nchunk - 1));
         if (!(ov && c < nchunk)) w[t] = f32x4{0, 0, 0, 0};
@@ -621,12 +623,12 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     stamp(1);
     float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < TCH; ++t) {
         const int c = min(sub + 16 * t, nchunk - 1);
         const f32x4 x = *(const f32x4*)(xs + 4 * c);
         acc += (w[t][0] * x[0] + w[t][1] * x[1]) + (w[t][2] * x[2] + w[t][3] * x[3]);
     }
-    for (int base = 256; base < nchunk; base += 256) {               // rows longer than 1024 elements
+    for (int base = 16 * TCH; base < nchunk; base += 256) {          // the rest of a longer row, from memory
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
             const int c = base + sub + 16 * t;
@@ -651,7 +653,8 @@ template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) 
     // many partial rows (SE fc1 partials, pooled ASPP input): 1024 threads so that one round of loads covers them
     const int nth = a.nparts > 16 ? 1024 : 256;
     const int opb = (nth / 64) * 4;
-    hipLaunchKernelGGL((gemv_act<T>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
+    if (a.I <= 256) hipLaunchKernelGGL((gemv_act<T, 4>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
+    else hipLaunchKernelGGL((gemv_act<T, 16>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
 }
 template void launch_gemv<f16>(const GemvArgs&, int, hipStream_t);
 template void launch_gemv<float>(const GemvArgs&, int, hipStream_t);
