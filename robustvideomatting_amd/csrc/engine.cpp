@@ -678,6 +678,7 @@ int build_plan(rvm_ctx* c) {
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
+    bool plan_bad = false;
     struct PwX { int act_post = 0, sstride = 1, sHi = 0, sWi = 0, sWo = 0; };
     auto pw = [&](const std::string& name, const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
                   const float* out_scale, float* pool, PwX ex = PwX()) {
@@ -686,6 +687,7 @@ int build_plan(rvm_ctx* c) {
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
+        if (in_scale && (L.KS * 32 > 1024 || L.Cin % 4)) { fail("pw_gemm: input scale vector too long"); plan_bad = true; return; }
         const int cfg = tune_pick(name, 7, pick_pw_cfg(a.MT, a.NT, a.KS, B));
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
@@ -1049,7 +1051,7 @@ int build_plan(rvm_ctx* c) {
                 });
         }
     }
-    return 0;
+    return plan_bad ? 1 : 0;
 }
 
 // Tile shapes by measurement.  With many frames per call (B*T > 1) a launch has blocks to spare and the

@@ -145,6 +145,37 @@ template <> __device__ __forceinline__ void load_scaled<f32s>(Frag<f32s>& f, con
     f.set(*(const f32x4*)pf * *(const f32x4*)sf, *(const f32x4*)(pf + 4) * *(const f32x4*)(sf + 4));
 }
 
+// Activation operand exactly as loaded from global memory.  Nothing is computed at the load (the hi/lo split of
+// the f32s type and the SE rescale both need the data, i.e. a wait for the load): the conversion to an MFMA
+// fragment happens where the fragment is used, K steps later, so the loads of a prefetch window stay in flight.
+template <typename T> struct XRaw;
+template <> struct XRaw<f16> {
+    f16x8 v;
+    __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
+    __device__ __forceinline__ void zero() { v = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    __device__ __forceinline__ Frag<f16> frag() const { Frag<f16> f; f.v = v; return f; }
+    __device__ __forceinline__ Frag<f16> frag(const f16* s) const { Frag<f16> f; f.v = v * *(const f16x8*)s; return f; }
+};
+template <> struct XRaw<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = a; }
+    __device__ __forceinline__ Frag<float> frag() const { Frag<float> f; f.lo = a; f.hi = b; return f; }
+    __device__ __forceinline__ Frag<float> frag(const float* s) const {
+        Frag<float> f; f.lo = a * *(const f32x4*)s; f.hi = b * *(const f32x4*)(s + 4); return f;
+    }
+};
+template <> struct XRaw<f32s> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const f32s* p) { a = *(const f32x4*)p; b = *(const f32x4*)((const float*)p + 4); }
+    __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = a; }
+    __device__ __forceinline__ Frag<f32s> frag() const { Frag<f32s> f; f.set(a, b); return f; }
+    __device__ __forceinline__ Frag<f32s> frag(const f32s* s) const {
+        const float* sf = (const float*)s;
+        Frag<f32s> f; f.set(a * *(const f32x4*)sf, b * *(const f32x4*)(sf + 4)); return f;
+    }
+};
+
 // acc(16 out-channels x 16 pixels) += W(16 x 32) * X(32 x 16)
 __device__ __forceinline__ void mma(f32x4& acc, const Frag<f32s>& w, const Frag<f32s>& x) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.lo, x.hi, acc, 0, 0, 0);
@@ -192,7 +223,21 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     const int mt0 = (blockIdx.x * (KSP > 1 ? 1 : WM) + wm) * MW;
     const int nt0 = (blockIdx.y * (KSP > 1 ? 1 : WN) + wn) * NW;
     const int n = blockIdx.z;
-    if (mt0 >= a.MT || nt0 >= a.NT) return;                  // uniform per block when KSP > 1
+    // SE rescale of the input channels (x * scale): the sample's scale vector (<= 1024 channels, host-checked) is
+    // requested first, parked in LDS behind the operand prefetch and applied where a fragment is used
+    extern __shared__ __attribute__((aligned(16))) char pw_smem[];
+    T* scl = (T*)pw_smem;
+    const bool has_sc = a.in_scale != nullptr;
+    const int sci = threadIdx.x * 4;
+    f32x4 scv = f32x4{0, 0, 0, 0};
+    if (has_sc && sci < a.Cin) scv = ld4f((const T*)a.in_scale + (size_t)n * a.Cin + sci);   // Cin % 4 == 0 for SE widths
+    auto stage_scale = [&]() {
+        if (has_sc) {
+            if (sci < a.KS * 32) st4f(scl + sci, scv);       // zeros beyond Cin
+            __syncthreads();
+        }
+    };
+    if (mt0 >= a.MT || nt0 >= a.NT) { stage_scale(); return; }   // uniform per block when KSP > 1
     const int l15 = lane & 15, g = lane >> 4;
 
     const T* xp[MW];
@@ -215,8 +260,6 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
         nv[ni] = (nt0 + ni) < a.NT;
         wp[ni] = (const T*)a.w + (size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 512;
     }
-    const T* sc = a.in_scale ? (const T*)a.in_scale + (size_t)n * a.Cin : nullptr;
-
     f32x4 acc[MW][NW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
@@ -224,19 +267,17 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
     constexpr int PF = 3;                                   // operand prefetch depth (K steps)
-    Frag<T> wf[PF][NW], xf[PF][MW];
-    auto load_step = [&](int ks, Frag<T>* wo, Frag<T>* xo) {
+    Frag<T> wf[PF][NW];
+    XRaw<T> xf[PF][MW];
+    auto load_step = [&](int ks, Frag<T>* wo, XRaw<T>* xo) {
         const int c = ks * 32 + g * 8;
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) wo[ni].loadw(wp[ni] + (size_t)ks * 512, lane);
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
-            if (pv[mi] && c < a.Cin) {
-                if (sc) load_scaled<T>(xo[mi], xp[mi] + ks * 32, sc + c);
-                else xo[mi].load(xp[mi] + ks * 32);
-            } else {
-                xo[mi].zero();
-            }
+            // always a load from a valid address (masked where the fragment is used): nothing here waits for data
+            const bool ok = pv[mi] && c < a.Cin;
+            xo[mi].load(ok ? xp[mi] + ks * 32 : (const T*)a.x);
         }
     };
     // this wave's K steps: k0, k0 + KSP, ...
@@ -244,15 +285,20 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     const int nst = KSP > 1 ? (a.KS - k0 + KSP - 1) / KSP : a.KS;     // may be 0 for a wave when KS < KSP
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_step(min(k0 + KSP * p, a.KS - 1), wf[p], xf[p]);
+    stage_scale();
     for (int j0 = 0; j0 < nst; j0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int j = j0 + p;
             if (j < nst) {
+                const int c = (k0 + KSP * j) * 32 + g * 8;
 #pragma unroll
-                for (int mi = 0; mi < MW; ++mi)
+                for (int mi = 0; mi < MW; ++mi) {
+                    Frag<T> xa = has_sc ? xf[p][mi].frag(scl + c) : xf[p][mi].frag();
+                    if (!(pv[mi] && c < a.Cin)) xa.zero();
 #pragma unroll
-                    for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xf[p][mi]);
+                    for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[p][ni], xa);
+                }
                 if (j + PF < nst) load_step(k0 + KSP * (j + PF), wf[p], xf[p]);
             }
         }
@@ -320,15 +366,16 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    const size_t lds = a.in_scale ? (size_t)a.KS * 32 * sizeof(T) : 0;       // the SE scale vector
     switch (cfg) {
-        case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2, 1>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((pw_gemm<T, 2, 1, 4, 1, 1>), dim3(cdiv(a.MT, 8), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 4), N), dim3(256), 0, s, a); break;
+        case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2, 1>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_gemm<T, 2, 1, 4, 1, 1>), dim3(cdiv(a.MT, 8), cdiv(a.NT, 1), N), dim3(256), lds, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 4), N), dim3(256), lds, s, a); break;
         // split-K over the 4 waves: block tile = MW x NW
-        case 4: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 1, 1, 4>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 2), N), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 1), N), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 1, 1, 4>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), lds, s, a); break;
+        case 5: hipLaunchKernelGGL((pw_gemm<T, 1, 2, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 2), N), dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 1, 1, 4>), dim3(cdiv(a.MT, 1), cdiv(a.NT, 1), N), dim3(256), lds, s, a); break;
     }
 }
 template void launch_pw<f16>(const PwArgs&, int, int, hipStream_t);
@@ -400,15 +447,17 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     // ---- E: expand into the LDS tile.  The first m-tile's pixel loads are issued before the weights are
     //      staged so that both round trips to L2 overlap.
     const int MT = (NPX + 15) >> 4;
-    Frag<T> xf[ED_KSMAX];
+    XRaw<T> xf[ED_KSMAX];                                            // as loaded; split / converted where used
     auto load_x = [&](int mt) {
         const int px = mt * 16 + l15;
         const bool pv = px < NPX;
         const T* xp = xb + (size_t)(pv ? px : 0) * a.xs + g * 8;
 #pragma unroll
         for (int ks = 0; ks < ED_KSMAX; ++ks) {
-            if (ks < a.KS && pv && ks * 32 + g * 8 < a.Cin) xf[ks].load(xp + ks * 32);
-            else xf[ks].zero();
+            if (ks < a.KS) {                                         // uniform; the loads themselves are branch-free
+                const bool ok = pv && ks * 32 + g * 8 < a.Cin;
+                xf[ks].load(ok ? xp + ks * 32 : xb);               // masked where the fragment is used
+            }
         }
     };
     if (a.w && wave < MT && !(a.dbg & 1)) load_x(wave);
@@ -452,7 +501,9 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
                 if (ks < a.KS) {
                     Frag<T> wf;
                     wf.loadw(we + (size_t)ks * 512, lane);
-                    mma(acc, wf, xf[ks]);
+                    Frag<T> xa = xf[ks].frag();
+                    if (!(px < NPX && ks * 32 + g * 8 < a.Cin)) xa.zero();
+                    mma(acc, wf, xa);
                 }
             }
             f32x4 v = acc + *(const f32x4*)(be + g * 4);
