@@ -286,6 +286,29 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_step(min(k0 + KSP * p, a.KS - 1), wf[p], xf[p]);
     stage_scale();
+    // epilogue operands (bias, residual, output gate) requested now: the epilogue would otherwise start with
+    // one more exposed round trip to L2
+    f32x4 e_bias[NW], e_osc[NW], e_res[MW][NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        const int ch = (nt0 + (nv[ni] ? ni : 0)) * 16 + g * 4;
+        e_bias[ni] = *(const f32x4*)(a.bias + ch);
+        e_osc[ni] = f32x4{1, 1, 1, 1};
+        if (a.out_scale) {
+            const f32x4 t = *(const f32x4*)(a.out_scale + (size_t)n * a.oss + min(ch, a.Cout - 4));
+            if (ch < a.Cout) e_osc[ni] = t;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            e_res[mi][ni] = f32x4{0, 0, 0, 0};
+            if (a.res && (KSP == 1 || ((mi * NW + ni) & 3) == wave)) {
+                const int pix = (mt0 + mi) * 16 + l15;
+                const bool ok = pv[mi] && nv[ni] && ch < a.Cout;
+                const f32x4 t = ld4f((const T*)a.res + (ok ? ((size_t)n * a.HW + pix) * a.rs + ch : 0));
+                if (ok) e_res[mi][ni] = t;
+            }
+        }
+    }
     for (int j0 = 0; j0 < nst; j0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -327,9 +350,8 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     for (int ni = 0; ni < NW; ++ni) {
         if (!nv[ni]) continue;
         const int ch = (nt0 + ni) * 16 + g * 4;
-        const f32x4 bias = *(const f32x4*)(a.bias + ch);
-        f32x4 osc = f32x4{1, 1, 1, 1};
-        if (a.out_scale && ch < a.Cout) osc = *(const f32x4*)(a.out_scale + (size_t)n * a.oss + ch);
+        const f32x4 bias = e_bias[ni];
+        const f32x4 osc = e_osc[ni];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             if (KSP > 1 && ((mi * NW + ni) & 3) != wave) continue;
@@ -341,7 +363,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
             }
             const bool ok = pv[mi] && ch < a.Cout;
             if (ok) {
-                if (a.res) v += ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + ch);
+                if (a.res) v += e_res[mi][ni];
                 if (a.act_post) {                            // resnet bottleneck: relu(bn(conv) + identity)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
@@ -395,7 +417,7 @@ template void launch_pw<f32s>(const PwArgs&, int, int, hipStream_t);
 //      [channel quad][pixel][4] so the depthwise reads are conflict-free.
 //   D: a wave owns one channel quad (uniform weights, LDS broadcast) x 64 consecutive output pixels.
 // ------------------------------------------------------------------------------------------
-constexpr int ED_KSMAX = 5;                                  // Cin <= 160
+[[maybe_unused]] constexpr int ED_KSMAX = 3;                                  // fused expand: Cin <= 96 (wider layers expand in their own GEMM)
 size_t ed_lds_bytes(int K, int KS, int npxs, int es) {
     return (size_t)4 * npxs * 16 + (size_t)KS * 512 * es + (size_t)(K * K * 16 + 32 + 16) * 4 + 4096;
 }
@@ -417,7 +439,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // The LDS tile is ZERO-PADDED like the convolution's input: tile row tr <-> input row r0*stride - pad + tr,
 // tile column tc <-> input column tc - pad, so a tap is a constant offset from the output's base address
 // (no clamps, no masks in the depthwise loop).
-template <typename T, int K>
+// KSE = K steps of the fused expand (0: the input is already expanded), compile-time so that the number of loads
+// in flight is known where a tile is consumed (a run-time count makes every wait a wait for ALL loads)
+template <typename T, int K, int KSE>
 __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,20 +471,19 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     // ---- E: expand into the LDS tile.  The first m-tile's pixel loads are issued before the weights are
     //      staged so that both round trips to L2 overlap.
     const int MT = (NPX + 15) >> 4;
-    XRaw<T> xf[ED_KSMAX];                                            // as loaded; split / converted where used
-    auto load_x = [&](int mt) {
+    constexpr int KSN = KSE > 0 ? KSE : 1;
+    XRaw<T> xfa[KSN], xfb[KSN];                                      // two m-tiles in flight; as loaded, split where used
+    auto load_x = [&](int mt, XRaw<T>* xf) {
         const int px = mt * 16 + l15;
         const bool pv = px < NPX;
         const T* xp = xb + (size_t)(pv ? px : 0) * a.xs + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < ED_KSMAX; ++ks) {
-            if (ks < a.KS) {                                         // uniform; the loads themselves are branch-free
-                const bool ok = pv && ks * 32 + g * 8 < a.Cin;
-                xf[ks].load(ok ? xp + ks * 32 : xb);               // masked where the fragment is used
-            }
+        for (int ks = 0; ks < KSN; ++ks) {                           // branch-free loads
+            const bool ok = pv && ks * 32 + g * 8 < a.Cin;
+            xf[ks].load(ok ? xp + ks * 32 : xb);                   // masked where the fragment is used
         }
     };
-    if (a.w && wave < MT && !(a.dbg & 1)) load_x(wave);
+    if (KSE > 0 && wave < MT && !(a.dbg & 1)) load_x(wave, xfa);
     // SE: this block's 16 columns of the fc1 rows, requested now, used after the depthwise pass
     f32x4 w1[4];
     if (a.hpart && tid < a.S && c0 + 16 <= a.C) {
@@ -491,30 +514,45 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     }
     __syncthreads();
     stamp(1);
-    if (a.w && !(a.dbg & 1)) {
-        for (int mt = wave; mt < MT; mt += 16) {
-            if (mt != wave) load_x(mt);
+    if (KSE > 0 && !(a.dbg & 1)) {
+        auto expand_tile = [&](int mt, const XRaw<T>* xf) {
             const int px = mt * 16 + l15;
             f32x4 acc = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < ED_KSMAX; ++ks) {
-                if (ks < a.KS) {
-                    Frag<T> wf;
-                    wf.loadw(we + (size_t)ks * 512, lane);
-                    Frag<T> xa = xf[ks].frag();
-                    if (!(px < NPX && ks * 32 + g * 8 < a.Cin)) xa.zero();
-                    mma(acc, wf, xa);
-                }
+            for (int ks = 0; ks < KSN; ++ks) {
+                Frag<T> wf;
+                wf.loadw(we + (size_t)ks * 512, lane);
+                Frag<T> xa = xf[ks].frag();
+                if (!(px < NPX && ks * 32 + g * 8 < a.Cin)) xa.zero();
+                mma(acc, wf, xa);
             }
             f32x4 v = acc + *(const f32x4*)(be + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.eact);
             if (px < NPX) ebuf[g * a.npxs + tile_index(px)] = v;
+        };
+        // the next tile's pixels are requested before the current tile is multiplied
+        for (int mt = wave; mt < MT; mt += 32) {
+            if (mt + 16 < MT) load_x(mt + 16, xfb);
+            expand_tile(mt, xfa);
+            if (mt + 32 < MT) load_x(mt + 32, xfa);
+            if (mt + 16 < MT) expand_tile(mt + 16, xfb);
         }
     } else {
-        for (int it = tid; it < NPX * 4; it += 1024) {
-            const int px = it >> 2, q = it & 3;
-            if (c0 + q * 4 < a.C) ebuf[q * a.npxs + tile_index(px)] = ld4f(xb + (size_t)px * a.xs + c0 + q * 4);
+        // already expanded input: copy the slice into the tile, 4 loads in flight per thread
+        for (int it0 = tid; it0 < NPX * 4; it0 += 4096) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * 1024, px = it >> 2, q = it & 3;
+                const bool ok = it < NPX * 4 && c0 + q * 4 < a.C;
+                v[u] = ld4f(xb + (ok ? (size_t)px * a.xs + c0 + q * 4 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * 1024, px = it >> 2, q = it & 3;
+                if (it < NPX * 4 && c0 + q * 4 < a.C) ebuf[q * a.npxs + tile_index(px)] = v[u];
+            }
         }
     }
     __syncthreads();
@@ -589,8 +627,11 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s) {
     dim3 grid((a.C + 15) / 16, a.nband, N);
     const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
-    if (K == 3) hipLaunchKernelGGL((mbconv_ed<T, 3>), grid, dim3(1024), lds, s, a);
-    else hipLaunchKernelGGL((mbconv_ed<T, 5>), grid, dim3(1024), lds, s, a);
+    const int kse = a.w ? a.KS : 0;                                  // 0..ED_KSMAX (host-checked)
+#define RVM_ED_CASE(KK, KS_) if (K == KK && kse == KS_) { hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); return; }
+    RVM_ED_CASE(3, 0) RVM_ED_CASE(3, 1) RVM_ED_CASE(3, 2) RVM_ED_CASE(3, 3)
+    RVM_ED_CASE(5, 0) RVM_ED_CASE(5, 1) RVM_ED_CASE(5, 2) RVM_ED_CASE(5, 3)
+#undef RVM_ED_CASE
 }
 template void launch_ed<f16>(const EdArgs&, int, int, hipStream_t);
 template void launch_ed<float>(const EdArgs&, int, int, hipStream_t);
@@ -1687,10 +1728,11 @@ void kernels_init() {
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
     (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define RVM_ED_ATTR(TT, KK) \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RVM_ED_ATTR(f16, 3) RVM_ED_ATTR(f16, 5) RVM_ED_ATTR(float, 3) RVM_ED_ATTR(float, 5) RVM_ED_ATTR(f32s, 3) RVM_ED_ATTR(f32s, 5)
+#undef RVM_ED_ATTR
 }
