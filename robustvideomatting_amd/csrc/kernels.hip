@@ -1183,6 +1183,15 @@ __global__ __launch_bounds__(256) void pyramid23(PoolArgs a) {
     if (p >= a.H3 * a.W3) return;
     const int y3 = p / a.W3, x3 = p - y3 * a.W3;
     const T* s1 = (const T*)a.s1 + (size_t)n * a.H1 * a.W1 * 4;
+    // the (up to) 4 x 4 s1 pixels are requested first (clamped coordinates): one round trip
+    f32x4 px1[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = min(4 * y3 + j, a.H1 - 1), ix = min(4 * x3 + i, a.W1 - 1);
+            px1[j][i] = ld4f(s1 + ((size_t)iy * a.W1 + ix) * 4);
+        }
     f32x4 acc3 = f32x4{0, 0, 0, 0};
     int cnt3 = 0;
 #pragma unroll
@@ -1198,7 +1207,7 @@ __global__ __launch_bounds__(256) void pyramid23(PoolArgs a) {
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int iy = 2 * y2 + dy, ix = 2 * x2 + dx;
-                    if (iy < a.H1 && ix < a.W1) { acc += ld4f(s1 + ((size_t)iy * a.W1 + ix) * 4); ++cnt; }
+                    if (iy < a.H1 && ix < a.W1) { acc += px1[2 * ey + dy][2 * ex + dx]; ++cnt; }
                 }
             acc = acc / (float)cnt;
 #pragma unroll
@@ -1363,48 +1372,63 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     const int y0 = ty * 16, x0 = tx * 16;
     const T* hid = (const T*)a.hid + (size_t)n * a.h * a.w * 16;
     const T* s0 = (const T*)a.s0 + (size_t)n * a.h * a.w * 4;
-    // MLP weight fragments: 18 KiB, 16-byte pieces
-    {
-        f32x4 wreg[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) wreg[j] = ((const f32x4*)a.mlp)[i]; }
-        for (int pp = tid; pp < 324; pp += 256) {
-            const int py = pp / 18, px = pp - py * 18;
-            const int gy = y0 + py - 1, gx = x0 + px - 1;
-            f32x4 xv = f32x4{0, 0, 0, 0}, yv = xv;
-            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) {
-                const size_t pix = (size_t)gy * a.w + gx;
-                xv = ld4f(s0 + pix * 4);
-                xv[3] = (xv[0] + xv[1] + xv[2]) / 3.f;
-                F8 h0 = ld8f(hid + pix * 16), h1 = ld8f(hid + pix * 16 + 8);
-                float hv[16];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { hv[k] = h0.lo[k]; hv[4 + k] = h0.hi[k]; hv[8 + k] = h1.lo[k]; hv[12 + k] = h1.hi[k]; }
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float sacc = wt.proj_b[o];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) sacc += wt.proj_w[o][k] * hv[k];
-                    yv[o] = sacc;
-                }
-            }
-            sx[pp] = xv; sy[pp] = yv;
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) ((f32x4*)wl)[i] = wreg[j]; }
-    }
-    // hid slices this lane supplies to the other three tiles of its wave (issued before the barrier)
+    // Everything this block reads from memory is requested up front, branch-free (clamped addresses, masked
+    // afterwards): MLP weight fragments (18 KiB, 16-byte pieces), the 18 x 18 halo of s0 | hid (two rounds of
+    // 256 threads) and the hid slices this lane supplies to the other three tiles of its wave.
     const int lane = tid & 63, lx = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int gx = x0 + lx;
     f32x4 hs[4][2];
+    {
+        f32x4 wreg[5];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int rg = (g - t) & 3;
-        const int gyt = y0 + 4 * wave + t;
-        hs[t][0] = hs[t][1] = f32x4{0, 0, 0, 0};
-        if ((rg == 1 || rg == 2) && gyt < a.h && gx < a.w) {
-            const F8 h = ld8f(hid + ((size_t)gyt * a.w + gx) * 16 + (rg - 1) * 8);
-            hs[t][0] = h.lo; hs[t][1] = h.hi;
+        for (int j = 0; j < 5; ++j) { const int i = min(tid + 256 * j, 1151); wreg[j] = ((const f32x4*)a.mlp)[i]; }
+        f32x4 xr[2]; F8 h0r[2], h1r[2]; bool inb[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pp = min(tid + 256 * r, 323);
+            const int py = pp / 18, px = pp - py * 18;
+            const int gy = y0 + py - 1, gxx = x0 + px - 1;
+            inb[r] = gy >= 0 && gy < a.h && gxx >= 0 && gxx < a.w;
+            const size_t pix = inb[r] ? (size_t)gy * a.w + gxx : 0;
+            xr[r] = ld4f(s0 + pix * 4);
+            h0r[r] = ld8f(hid + pix * 16); h1r[r] = ld8f(hid + pix * 16 + 8);
+        }
+        F8 hsr[4]; bool hsok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rg = (g - t) & 3;
+            const int gyt = y0 + 4 * wave + t;
+            hsok[t] = (rg == 1 || rg == 2) && gyt < a.h && gx < a.w;
+            hsr[t] = ld8f(hid + (hsok[t] ? ((size_t)gyt * a.w + gx) * 16 + (rg - 1) * 8 : 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pp = tid + 256 * r;
+            if (pp < 324) {
+                f32x4 xv = f32x4{0, 0, 0, 0}, yv = xv;
+                if (inb[r]) {
+                    xv = xr[r];
+                    xv[3] = (xv[0] + xv[1] + xv[2]) / 3.f;
+                    float hv[16];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { hv[k] = h0r[r].lo[k]; hv[4 + k] = h0r[r].hi[k]; hv[8 + k] = h1r[r].lo[k]; hv[12 + k] = h1r[r].hi[k]; }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        float sacc = wt.proj_b[o];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) sacc += wt.proj_w[o][k] * hv[k];
+                        yv[o] = sacc;
+                    }
+                }
+                sx[pp] = xv; sy[pp] = yv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) ((f32x4*)wl)[i] = wreg[j]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            hs[t][0] = hsok[t] ? hsr[t].lo : f32x4{0, 0, 0, 0};
+            hs[t][1] = hsok[t] ? hsr[t].hi : f32x4{0, 0, 0, 0};
         }
     }
     __syncthreads();
