@@ -80,6 +80,23 @@ enum { RVM_COMPOSE_GREEN = 0, RVM_COMPOSE_RGBA = 1, RVM_COMPOSE_ALPHA = 2, RVM_C
 int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_t* out, int N, int H, int W,
                    const float bgr[3], void* hip_stream);
 
+/* Matting quality metrics of the reference's evaluator (evaluation/evaluate_hr.py:176-235) on device tensors,
+ * one pass over a clip of N consecutive frames (fp32, values 0..1, as the evaluator feeds them: image / 255):
+ *   sums[n][0] = sum |pred - true|                     MetricMAD  (:176-178)  = sums0 / (H*W) * 1e3
+ *   sums[n][1] = sum (pred - true)^2                   MetricMSE  (:181-183)  = sums1 / (H*W) * 1e3
+ *   sums[n][2] = sum (|grad true| - |grad pred|)^2     MetricGRAD (:186-227)  = sums2 / 1000
+ *                (9 x 9 Gaussian-derivative filters for `sigma` = 1.4, cross-correlation, replicate border)
+ *   sums[n][3] = sum ((pred_n - pred_n-1) - (true_n - true_n-1))^2   MetricDTSSD (:230-235) = sqrt(sums3 / (H*W)) * 1e2;
+ *                frame 0 uses pred_prev / true_prev ([H,W]; both NULL: 0, the evaluator's first frame :151-152)
+ *   sums[n][4], sums[n][5] = sum of squared foreground error over true_pha > 0 and the number of elements in it
+ *                (fgr_mse :169-171 = sums4 / sums5 * 1e3); pred_fgr / true_fgr are [N,3,H,W] or both NULL.
+ * `sums` is a DEVICE array of N*6 doubles; `workspace` a device buffer of rvm_metrics_workspace(N,H,W) bytes.
+ * Asynchronous on `hip_stream`; deterministic (fixed summation order). */
+int64_t rvm_metrics_workspace(int N, int H, int W);
+int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                void* workspace, double* sums, void* hip_stream);
+
 /* Debug / test taps: copy an intermediate activation of the LAST forward to host as fp32 NCHW.
  * Names: s0 s1 s2 s3 f1 f2 f3 f4 aspp x3 x2 x1 hid ab.  Synchronises the device. */
 int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capacity, int64_t shape[4]);

@@ -136,6 +136,20 @@ enum ComposeMode { COMPOSE_GREEN = 0, COMPOSE_RGBA = 1, COMPOSE_ALPHA = 2, COMPO
 struct ComposeArgs { const void* fgr; const void* pha; unsigned char* out; int H, W, mode; float bgr[3]; };
 void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s);
 
+// ---- matting quality metrics (reference evaluation/evaluate_hr.py:176-235) ------------------------
+constexpr int METRIC_TILE = 32;             // output tile edge of matte_metrics
+constexpr int METRIC_NSUM = 6;              // |d|, d^2, grad^2, dt^2, masked fgr d^2, masked element count
+struct MetricArgs {
+    const float* pred; const float* tru;            // [N][H][W] alpha in 0..1
+    const float* pred_prev; const float* tru_prev;  // [H][W] frame in front of frame 0 (nullptr: none)
+    const float* pred_fgr; const float* tru_fgr;    // [N][3][H][W] (nullptr: no foreground metric)
+    float* partial;                                 // [N][blocks][METRIC_NSUM]
+    double* out;                                    // [N][METRIC_NSUM]
+    int H, W, tiles_x, tiles_y;
+    float g[9], dg[9];                              // separable 9x9 Gaussian-derivative filter: K[i][j] = g[i] * dg[j]
+};
+void launch_metrics(const MetricArgs& a, int N, hipStream_t s);
+
 // launchers (kernels.hip)
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);

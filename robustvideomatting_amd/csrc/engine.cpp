@@ -1326,6 +1326,41 @@ int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_
     return 0;
 }
 
+int64_t rvm_metrics_workspace(int N, int H, int W) {
+    if (N < 1 || H < 1 || W < 1) return -1;
+    return (int64_t)N * cdiv(W, METRIC_TILE) * cdiv(H, METRIC_TILE) * METRIC_NSUM * (int64_t)sizeof(float);
+}
+
+int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                void* workspace, double* sums, void* hip_stream) {
+    if (!pred_pha || !true_pha || !workspace || !sums) return fail("rvm_metrics: null buffer");
+    if (N < 1 || N > 65535 || H < 1 || W < 1) return fail("rvm_metrics: bad shape");
+    if ((pred_prev == nullptr) != (true_prev == nullptr)) return fail("rvm_metrics: previous frames come in pairs");
+    if ((pred_fgr == nullptr) != (true_fgr == nullptr)) return fail("rvm_metrics: foregrounds come in pairs");
+    // Gaussian-derivative filter of evaluate_hr.py:203-227 (sigma 1.4 -> 9 x 9), factored: K[i][j] = g[i] * dg[j]
+    const double eps = 1e-2;
+    const int half = (int)std::ceil(sigma * std::sqrt(-2.0 * std::log(std::sqrt(2.0 * M_PI) * sigma * eps)));
+    if (half != 4) return fail("rvm_metrics: the kernel is built for the 9 x 9 filter (sigma 1.4 of the reference)");
+    double g[9], dg[9], sg = 0.0, sd = 0.0;
+    for (int i = 0; i < 9; ++i) {
+        const double x = i - half;
+        g[i] = std::exp(-x * x / (2 * sigma * sigma)) / (sigma * std::sqrt(2.0 * M_PI));
+        dg[i] = -x * g[i] / (sigma * sigma);
+        sg += g[i] * g[i]; sd += dg[i] * dg[i];
+    }
+    const double norm = std::sqrt(sg * sd);                 // sqrt(sum K^2), :215
+    MetricArgs a; memset(&a, 0, sizeof a);
+    for (int i = 0; i < 9; ++i) { a.g[i] = (float)(g[i] / std::sqrt(norm)); a.dg[i] = (float)(dg[i] / std::sqrt(norm)); }
+    a.pred = pred_pha; a.tru = true_pha; a.pred_prev = pred_prev; a.tru_prev = true_prev;
+    a.pred_fgr = pred_fgr; a.tru_fgr = true_fgr; a.partial = (float*)workspace; a.out = sums;
+    a.H = H; a.W = W; a.tiles_x = cdiv(W, METRIC_TILE); a.tiles_y = cdiv(H, METRIC_TILE);
+    if (a.tiles_y > 65535) return fail("rvm_metrics: frame too tall");
+    launch_metrics(a, N, (hipStream_t)hip_stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
     if (!out || capacity < 2 * 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 2*512*16 values");
     unsigned int n[2] = {0, 0};

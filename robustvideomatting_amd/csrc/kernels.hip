@@ -1723,6 +1723,105 @@ void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Matting quality metrics of the reference's evaluator (evaluation/evaluate_hr.py:176-235), one pass over a
+// clip: MAD (:176-178), MSE (:181-183), GRAD (:186-227: 9x9 Gaussian-derivative filters, sigma 1.4,
+// cross-correlation with replicate border as kornia.filters.filter2d does it, magnitude, squared
+// difference summed), dtSSD (:230-235) and the foreground MSE over true_pha > 0 (:169-171).
+// Block = one 32 x 32 tile of one frame: the 40 x 40 halo of both mattes goes to LDS, the filter runs
+// separably (rows then columns) out of LDS, and the block leaves six partial sums; a second launch adds the
+// partial sums of a frame in a fixed order in double precision.  HBM-bound: every input is read once.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void matte_metrics(MetricArgs a) {
+    constexpr int TS = METRIC_TILE, R = 4, PS = TS + 2 * R;             // 40
+    __shared__ float im[2][PS][PS + 1];                                 // pred, true with halo
+    __shared__ float hx[2][PS][TS + 1], hg[2][PS][TS + 1];              // row pass: derivative / smoothing along x
+    __shared__ float red[4][METRIC_NSUM];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const size_t plane = (size_t)a.H * a.W;
+    const float* P = a.pred + (size_t)n * plane;
+    const float* T = a.tru + (size_t)n * plane;
+    for (int i = tid; i < PS * PS; i += 256) {
+        const int py = i / PS, px = i - py * PS;
+        const int gy = min(max(y0 + py - R, 0), a.H - 1), gx = min(max(x0 + px - R, 0), a.W - 1);   // replicate border
+        im[0][py][px] = P[(size_t)gy * a.W + gx];
+        im[1][py][px] = T[(size_t)gy * a.W + gx];
+    }
+    __syncthreads();
+    float s[METRIC_NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- pointwise sums over the tile's own pixels
+    const float* Pp = n > 0 ? P - plane : a.pred_prev;
+    const float* Tp = n > 0 ? T - plane : a.tru_prev;
+    for (int i = tid; i < TS * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= a.H || gx >= a.W) continue;
+        const float p = im[0][ly + R][lx + R], t = im[1][ly + R][lx + R];
+        const float d = p - t;
+        s[0] += fabsf(d);
+        s[1] += d * d;
+        if (Pp) {
+            const size_t o = (size_t)gy * a.W + gx;
+            const float dt = (p - Pp[o]) - (t - Tp[o]);
+            s[3] += dt * dt;
+        }
+        if (a.pred_fgr && t > 0.f) {
+            const size_t o = (size_t)n * 3 * plane + (size_t)gy * a.W + gx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float e = a.pred_fgr[o + c * plane] - a.tru_fgr[o + c * plane]; s[4] += e * e; }
+            s[5] += 3.f;
+        }
+    }
+    // ---- row pass of the separable filter
+    for (int i = tid; i < 2 * PS * TS; i += 256) {
+        const int m = i / (PS * TS), r = (i - m * PS * TS) / TS, c = i % TS;
+        float ax = 0.f, ag = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { const float v = im[m][r][c + j]; ax += a.dg[j] * v; ag += a.g[j] * v; }
+        hx[m][r][c] = ax; hg[m][r][c] = ag;
+    }
+    __syncthreads();
+    // ---- column pass, gradient magnitude, squared difference
+    for (int i = tid; i < TS * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        if (y0 + ly >= a.H || x0 + lx >= a.W) continue;
+        float mag[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float fx = 0.f, fy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { fx += a.g[k] * hx[m][ly + k][lx]; fy += a.dg[k] * hg[m][ly + k][lx]; }
+            mag[m] = sqrtf(fx * fx + fy * fy);
+        }
+        const float e = mag[1] - mag[0];
+        s[2] += e * e;
+    }
+    // ---- block sums (fixed order)
+#pragma unroll
+    for (int k = 0; k < METRIC_NSUM; ++k) s[k] = wave_sum(s[k]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < METRIC_NSUM; ++k) red[tid >> 6][k] = s[k];
+    }
+    __syncthreads();
+    if (tid < METRIC_NSUM) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+        a.partial[((size_t)n * nblk + blk) * METRIC_NSUM + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+__global__ __launch_bounds__(64) void matte_metrics_sum(MetricArgs a, int nblk) {
+    const int n = blockIdx.x, k = threadIdx.x;
+    if (k >= METRIC_NSUM) return;
+    double acc = 0.0;
+    for (int b = 0; b < nblk; ++b) acc += (double)a.partial[((size_t)n * nblk + b) * METRIC_NSUM + k];
+    a.out[(size_t)n * METRIC_NSUM + k] = acc;
+}
+void launch_metrics(const MetricArgs& a, int N, hipStream_t s) {
+    hipLaunchKernelGGL(matte_metrics, dim3(a.tiles_x, a.tiles_y, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(matte_metrics_sum, dim3(N), dim3(64), 0, s, a, a.tiles_x * a.tiles_y);
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool on NHWC (torchvision ResNet.maxpool, reference resnet.py:25).
 // ------------------------------------------------------------------------------------------
 template <typename T>

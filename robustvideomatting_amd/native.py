@@ -19,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward",
-    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -70,6 +70,11 @@ def lib():
     L.rvm_debug_stamps.restype = ci
     L.rvm_compose_u8.argtypes = [ci, ci, vp, vp, vp, ci, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
     L.rvm_compose_u8.restype = ci
+    fp = ctypes.c_void_p
+    L.rvm_metrics_workspace.argtypes = [ci, ci, ci]
+    L.rvm_metrics_workspace.restype = ctypes.c_int64
+    L.rvm_metrics.argtypes = [fp, fp, fp, fp, fp, fp, ci, ci, ci, ctypes.c_double, vp, vp, vp]
+    L.rvm_metrics.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
     L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
@@ -95,6 +100,20 @@ def compose_u8(dtype_code, mode, fgr_ptr, pha_ptr, out_ptr, N, H, W, bgr, stream
     c3 = (ctypes.c_float * 3)(*(bgr if bgr is not None else (0.0, 0.0, 0.0)))
     check(lib().rvm_compose_u8(dtype_code, mode, ctypes.c_void_p(fgr_ptr) if fgr_ptr else None, ctypes.c_void_p(pha_ptr),
                                ctypes.c_void_p(out_ptr), N, H, W, c3, ctypes.c_void_p(stream)), "rvm_compose_u8")
+
+
+def metrics_workspace(N, H, W):
+    n = lib().rvm_metrics_workspace(N, H, W)
+    if n < 0:
+        raise NativeError("rvm_metrics_workspace: bad shape")
+    return n
+
+
+def metrics(pred, true, pred_prev, true_prev, pred_fgr, true_fgr, N, H, W, sigma, workspace, sums, stream):
+    """rvm_metrics on raw device pointers (0 = absent)."""
+    P = lambda p: ctypes.c_void_p(p) if p else None
+    check(lib().rvm_metrics(P(pred), P(true), P(pred_prev), P(true_prev), P(pred_fgr), P(true_fgr), N, H, W, float(sigma),
+                            P(workspace), P(sums), P(stream)), "rvm_metrics")
 
 
 def debug_stamps():
