@@ -830,7 +830,10 @@ int build_plan(rvm_ctx* c) {
                 { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
                 if (a.KS > 3 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * Wi >= 65536 || (b.has_se && b.se.S > 1024))
                     return fail("mbconv_ed: unsupported block shape");
-                const int nparts = nslice * a.nband;
+                // an already expanded layer with few 16-channel blocks (the 1/16-scale layers: <= 60 on 256 CUs) splits
+                // into 8-channel blocks: half the depthwise work per block, twice the CUs
+                a.cw = (!fuse_e && b.has_expand && exp % 8 == 0 && nslice * a.nband * B <= 128) ? 8 : 16;
+                const int nparts = cdiv(exp, a.cw) * a.nband;
                 float* hpart = nullptr;
                 if (b.has_se) {
                     hpart = fbuf((size_t)B * nparts * b.se.S);

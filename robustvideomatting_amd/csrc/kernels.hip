@@ -447,7 +447,8 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int slice = blockIdx.x, band = blockIdx.y, n = blockIdx.z;
-    const int c0 = slice * 16;
+    // a block owns a.cw channels: 16, or 8 for the already expanded layers whose grid would leave CUs idle
+    const int c0 = slice * a.cw, cend = min(a.C, c0 + a.cw), nq = a.cw >> 2, nqlog = a.cw == 8 ? 1 : 2;
     const int r0 = band * a.rb, r1 = min(r0 + a.rb, a.Ho);
     const int t_lo = r0 * a.stride - a.pad;                          // input row of tile row 0 (may be negative)
     const int trows = (r1 - r0 - 1) * a.stride + (K - 1) * a.dil + 1;
@@ -486,9 +487,12 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     if (KSE > 0 && wave < MT && !(a.dbg & 1)) load_x(wave, xfa);
     // SE: this block's 16 columns of the fc1 rows, requested now, used after the depthwise pass
     f32x4 w1[4];
-    if (a.hpart && tid < a.S && c0 + 16 <= a.C) {
+    if (a.hpart && tid < a.S && c0 + a.cw <= a.C) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w1[q] = *(const f32x4*)(a.fc1_w + (size_t)tid * a.C + c0 + q * 4);
+        for (int q = 0; q < 4; ++q) {
+            w1[q] = f32x4{0, 0, 0, 0};
+            if (q < nq) w1[q] = *(const f32x4*)(a.fc1_w + (size_t)tid * a.C + c0 + q * 4);
+        }
     }
     // weights of this channel slice into LDS, zero the tile
     {
@@ -497,10 +501,10 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         const char* src = (const char*)a.w + (size_t)slice * a.KS * 512 * sizeof(T);
         if (tid < pieces) wreg[0] = *(const f32x4*)(src + (size_t)tid * 16);
         float dwv = 0.f, bdv = 0.f, bev = 0.f;
-        if (tid < K * K * 16) { const int c = c0 + (tid & 15); if (c < a.C) dwv = a.dw_w[(size_t)(tid >> 4) * a.C + c]; }
+        if (tid < K * K * 16) { const int c = c0 + (tid & 15); if (c < cend) dwv = a.dw_w[(size_t)(tid >> 4) * a.C + c]; }
         if (tid >= 1024 - 16) {
             const int c = c0 + (tid & 15);
-            if (c < a.C) bdv = a.dw_b[c];
+            if (c < cend) bdv = a.dw_b[c];
             if (a.w) bev = a.ebias[c];
         }
         const int tcells = trows * PWt;
@@ -540,18 +544,18 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         }
     } else {
         // already expanded input: copy the slice into the tile, 4 loads in flight per thread
-        for (int it0 = tid; it0 < NPX * 4; it0 += 4096) {
+        for (int it0 = tid; it0 < NPX * nq; it0 += 4096) {
             f32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * 1024, px = it >> 2, q = it & 3;
-                const bool ok = it < NPX * 4 && c0 + q * 4 < a.C;
+                const int it = it0 + u * 1024, px = it >> nqlog, q = it & (nq - 1);
+                const bool ok = it < NPX * nq && c0 + q * 4 < cend;
                 v[u] = ld4f(xb + (ok ? (size_t)px * a.xs + c0 + q * 4 : 0));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * 1024, px = it >> 2, q = it & 3;
-                if (it < NPX * 4 && c0 + q * 4 < a.C) ebuf[q * a.npxs + tile_index(px)] = v[u];
+                const int it = it0 + u * 1024, px = it >> nqlog, q = it & (nq - 1);
+                if (it < NPX * nq && c0 + q * 4 < cend) ebuf[q * a.npxs + tile_index(px)] = v[u];
             }
         }
     }
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C;
     const unsigned invWo = 0xFFFFFFFFu / (unsigned)a.Wo + 1u;
     const int rowstep = a.dil * PWt;
-    for (int it = tid; it < 4 * npo_pad; it += 1024) {
+    for (int it = tid; it < nq * npo_pad; it += 1024) {
         const int q = it / npo_pad, p = it - q * npo_pad;            // q is wave-uniform
         const bool valid = p < npo;
         const int pp = valid ? p : 0;
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = act_f(acc[r], a.dact);
-        const bool cok = c0 + q * 4 < a.C;
+        const bool cok = c0 + q * 4 < cend;
         if (valid && cok && !(a.dbg & 4)) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
         if (a.hpart) {
             f32x4 s4;
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
                 for (int j = 0; j < 8; ++j) v[j] = (j0 + j < wpq) ? red[q * wpq + min(j0 + j, wpq - 1)][r] : 0.f;
                 s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
-            psum[tid] = (c0 + tid < a.C) ? s : 0.f;
+            psum[tid] = (c0 + tid < cend) ? s : 0.f;
         }
         __syncthreads();
         // fc1 partial: h[s] = sum_c W1[s][c0 + c] * psum[c]
@@ -611,13 +615,13 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         float* hp = a.hpart + ((size_t)n * nparts + slice * a.nband + band) * a.S;
         if (tid < a.S) {
             float h = 0.f;
-            if (c0 + 16 <= a.C) {
+            if (c0 + a.cw <= a.C) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     h += w1[q][0] * psum[q * 4] + w1[q][1] * psum[q * 4 + 1] + w1[q][2] * psum[q * 4 + 2] + w1[q][3] * psum[q * 4 + 3];
             } else {
                 const float* wr = a.fc1_w + (size_t)tid * a.C + c0;
-                for (int c = 0; c0 + c < a.C; ++c) h += wr[c] * psum[c];
+                for (int c = 0; c0 + c < cend; ++c) h += wr[c] * psum[c];
             }
             hp[tid] = h;
         }
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     stamp(4);
 }
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s) {
-    dim3 grid((a.C + 15) / 16, a.nband, N);
+    dim3 grid((a.C + a.cw - 1) / a.cw, a.nband, N);
     const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
     const int kse = a.w ? a.KS : 0;                                  // 0..ED_KSMAX (host-checked)
 #define RVM_ED_CASE(KK, KS_) if (K == KK && kse == KS_) { hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); return; }
@@ -651,23 +655,25 @@ template <int N> __device__ __forceinline__ float row_shr_add(float v) {
 // 4-element chunks sub, sub+16, ... of the weight row (coalesced 256 B per row and round).  The weight
 // chunks and the bias are requested before the input vector is reduced, so the two global round trips
 // overlap; the dot products finish with 4 DPP adds.
-// TCH = 4-element chunks of a weight row per lane: 4 covers rows of up to 256 inputs (every SE layer), 16 up to 1024
-// in registers (longer rows continue from memory).
-template <typename T, int TCH>
+// LPO = lanes per output: 16 (a wave owns 4 outputs: the SE layers, rows of <= 256 inputs) or 64 (one output per
+// wave: long rows such as the 960-input ASPP gate, spread over 4x as many blocks).  TCH = 4-element chunks of a
+// weight row per lane held in registers (LPO * TCH * 4 inputs; longer rows continue from memory).
+template <typename T, int TCH, int LPO>
 __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ float part[1024];
     const int n = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, row = lane >> 4, sub = lane & 15;
-    const int o = (blockIdx.x * (NTH >> 6) + wave) * 4 + row;
+    constexpr int OPW = 64 / LPO;                                    // outputs per wave
+    const int wave = tid >> 6, lane = tid & 63, row = lane / LPO, sub = lane % LPO;
+    const int o = (blockIdx.x * (NTH >> 6) + wave) * OPW + row;
     const bool ov = o < a.O;
     const int nchunk = a.I >> 2;                                     // I % 4 == 0 (host-checked)
     const T* wrow = (const T*)a.w + (size_t)(ov ? o : 0) * a.I;
     f32x4 w[TCH];
 #pragma unroll
     for (int t = 0; t < TCH; ++t) {
-        const int c = sub + 16 * t;
+        const int c = sub + LPO * t;
         w[t] = ld4f(wrow + 4 * min(c, nchunk - 1));
         if (!(ov && c < nchunk)) w[t] = f32x4{0, 0, 0, 0};
     }
@@ -716,25 +722,29 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     float acc = 0.f;
 #pragma unroll
     for (int t = 0; t < TCH; ++t) {
-        const int c = min(sub + 16 * t, nchunk - 1);
+        const int c = min(sub + LPO * t, nchunk - 1);
         const f32x4 x = *(const f32x4*)(xs + 4 * c);
         acc += (w[t][0] * x[0] + w[t][1] * x[1]) + (w[t][2] * x[2] + w[t][3] * x[3]);
     }
-    for (int base = 16 * TCH; base < nchunk; base += 256) {          // the rest of a longer row, from memory
+    for (int base = LPO * TCH; base < nchunk; base += LPO * 16) {    // the rest of a longer row, from memory
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
-            const int c = base + sub + 16 * t;
+            const int c = base + sub + LPO * t;
             if (ov && c < nchunk) {
                 const f32x4 wv = ld4f(wrow + 4 * c), x = *(const f32x4*)(xs + 4 * c);
                 acc += (wv[0] * x[0] + wv[1] * x[1]) + (wv[2] * x[2] + wv[3] * x[3]);
             }
         }
     }
-    acc = row_shr_add<1>(acc);
-    acc = row_shr_add<2>(acc);
-    acc = row_shr_add<4>(acc);
-    acc = row_shr_add<8>(acc);                                       // lane 15 of the row holds the sum
-    if (sub == 15 && ov) {
+    if constexpr (LPO == 16) {
+        acc = row_shr_add<1>(acc);
+        acc = row_shr_add<2>(acc);
+        acc = row_shr_add<4>(acc);
+        acc = row_shr_add<8>(acc);                                   // lane 15 of the row holds the sum
+    } else {
+        acc = wave_sum(acc);                                         // every lane holds the sum
+    }
+    if (sub == LPO - 1 && ov) {
         const float r = act_f(acc + bias, a.act);
         if (a.y_is_T) ((T*)a.y)[(size_t)n * a.O + o] = (T)r;
         else ((float*)a.y)[(size_t)n * a.O + o] = r;
@@ -744,9 +754,13 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s) {
     // many partial rows (SE fc1 partials, pooled ASPP input): 1024 threads so that one round of loads covers them
     const int nth = a.nparts > 16 ? 1024 : 256;
-    const int opb = (nth / 64) * 4;
-    if (a.I <= 256) hipLaunchKernelGGL((gemv_act<T, 4>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
-    else hipLaunchKernelGGL((gemv_act<T, 16>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
+    if (a.I <= 256) {
+        const int opb = (nth / 64) * 4;
+        hipLaunchKernelGGL((gemv_act<T, 4, 16>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
+    } else {
+        const int opb = nth / 64;
+        hipLaunchKernelGGL((gemv_act<T, 4, 64>), dim3((a.O + opb - 1) / opb, N), dim3(nth), (size_t)a.I * sizeof(float), s, a);
+    }
 }
 template void launch_gemv<f16>(const GemvArgs&, int, hipStream_t);
 template void launch_gemv<float>(const GemvArgs&, int, hipStream_t);
