@@ -801,15 +801,18 @@ int build_plan(rvm_ctx* c) {
                 int rb = Ho;
                 const int se_parts = 256;       // partial rows the squeeze-excite gemv sums per sample (measured: 64 / 128 / 256 -> 2275 / 2283 / 2290 fps)
                 {
+                    int valid[16], nvalid = 0, model = -1;
                     double best = 1e30;
-                    for (int cand = Ho; cand >= 1; cand = cand > 1 ? cdiv(cand, 2) : 0) {
+                    for (int cand = Ho; cand >= 1 && nvalid < 16; cand = cand > 1 ? cdiv(cand, 2) : 0) {
                         const int bands = cdiv(Ho, cand);
-                        if (lds_for(cand) > 150 * 1024) continue;
+                        if (lds_for(cand) > 150 * 1024 || rup(cand * Wo, 64) > 4096 || rows_for(cand) * Wi >= 65536) continue;
                         if (b.has_se && nslice * bands > se_parts && cand != Ho) continue;
                         const double cost = (double)cdiv(nslice * bands * B, 256) * (trows_for(cand) + 2);   // + fixed per-block part
-                        if (cost < best - 1e-9) { best = cost; rb = cand; }
+                        if (cost < best - 1e-9) { best = cost; model = nvalid; }
+                        valid[nvalid++] = cand;
                     }
-                    if (best > 1e29) return fail("mbconv_ed: tile does not fit LDS");
+                    if (nvalid == 0) return fail("mbconv_ed: tile does not fit LDS");
+                    rb = valid[tune_pick("mb" + std::to_string(i + 1) + ".ed", nvalid, model)];
                 }
                 EdArgs a; memset(&a, 0, sizeof a);
                 a.x = cur; a.Cin = curC; a.xs = curC;
@@ -1090,18 +1093,30 @@ int autotune(rvm_ctx* c) {
     const bool verbose = getenv("RVM_VERBOSE") != nullptr;
     for (const auto& t : tunable) {
         if (t.ncand < 2) continue;
-        int idx = -1;
-        for (size_t i = 0; i < c->launches.size() && idx < 0; ++i)
-            if (tune_key(c->launches[i].name) == t.key) idx = (int)i;
-        if (idx < 0) continue;
-        float best = 1e30f; int bestk = 0;
+        // the launches a key stands for: the one of that name, or - for "mbN.ed", the band height of the fused
+        // expand -> depthwise kernel - that kernel together with the separate expand GEMM some heights imply
+        const bool ed = t.key.size() > 3 && t.key.compare(t.key.size() - 3, 3, ".ed") == 0;
+        const std::string stem = ed ? t.key.substr(0, t.key.size() - 2) : std::string();      // "mbN."
+        auto members = [&]() {
+            std::vector<int> m;
+            for (size_t i = 0; i < c->launches.size(); ++i) {
+                const std::string& nm = c->launches[i].name;
+                if (ed ? (nm.compare(0, stem.size(), stem) == 0 && (nm.find("expand") != std::string::npos || nm.find(".dw") != std::string::npos))
+                       : tune_key(nm) == t.key) { m.push_back((int)i); if (!ed) break; }
+            }
+            return m;
+        };
+        if (members().empty()) continue;
+        float best = 1e30f; int bestk = t.model;
         for (int k = 0; k < t.ncand; ++k) {
             c->tuned[t.key] = k;
             if ((rc = rebuild())) { cleanup(); return rc; }
-            const int warm = 2, reps = 6;
-            for (int r = 0; r < warm; ++r) c->launches[idx].fn(st, io);
+            if (c->arena_used + 256 > c->arena_bytes) continue;          // this candidate needs a bigger arena than the model's plan
+            const std::vector<int> mem = members();
+            const int warm = 3, reps = 10;
+            for (int r = 0; r < warm; ++r) for (int i : mem) c->launches[i].fn(st, io);
             TUNECHK(hipEventRecord(e0, st));
-            for (int r = 0; r < reps; ++r) c->launches[idx].fn(st, io);
+            for (int r = 0; r < reps; ++r) for (int i : mem) c->launches[i].fn(st, io);
             TUNECHK(hipEventRecord(e1, st));
             TUNECHK(hipStreamSynchronize(st));
             TUNECHK(hipGetLastError());
@@ -1114,7 +1129,9 @@ int autotune(rvm_ctx* c) {
     }
 #undef TUNECHK
     cleanup();
-    return rebuild();
+    if ((rc = rebuild())) return rc;
+    if (c->arena_used + 256 > c->arena_bytes) return fail("autotune: chosen plan outgrew the arena");
+    return 0;
 }
 
 int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
