@@ -134,6 +134,38 @@ def test_resnet50_fp16fast(gc):
     assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
 
 
+def test_fp16_hd_batch4_autotuned_plan(gc):
+    """4 HD streams batched (the per-GPU side of BASELINE configs[4], scaled down): B*T > 1, so every GEMM / conv
+    tile was picked by plan-time measurement - whatever was picked has to stay inside the fp16 bound."""
+    w = gc.run("fp16", H=1080, W=1920, ds=0.25, T=1, B=4, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+
+
+# ------------------------------------------------------------------ shape sweep
+@pytest.mark.parametrize("H,W,ds,B", [
+    (97, 131, 0.5, 1),        # odd everything; low-res 48x65
+    (64, 64, 1.0, 3),         # no refiner, batch 3
+    (45, 77, 0.37, 2),        # ratio that is no power of two, tiny pyramid (16x28 -> 1x2 at 1/16)
+    (200, 360, 0.6, 1),       # larger low-res frame: several bands / tiles per level
+    (33, 520, 0.25, 1),       # very wide, 8 rows low-res
+])
+def test_fp32_shape_sweep_framewise_and_chunked(gc, H, W, ds, B):
+    """Band / tile / slice edges of every kernel on shapes unlike the benchmark's, frame by frame (all taps) and as
+    one chunk (plan-time tile measurement is active whenever B*T > 1)."""
+    w = gc.run("fp32", H=H, W=W, ds=ds, T=2, B=B, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    from oracle import rvm_oracle as O
+    from robustvideomatting_amd import synthetic
+    m, p = _setup(torch.float32)
+    clip = synthetic.make_clip(3, H, W, seed=3, B=B)
+    want = O.forward(p, clip, downsample_ratio=ds)
+    with torch.no_grad():
+        got = m(clip.cuda(), downsample_ratio=ds)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and (a.cpu() - b).abs().max() < TOL32
+
+
 # ------------------------------------------------------------------ golden fixture (no oracle involved)
 @pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast", "resnet50_ds025"])
 def test_against_committed_fixture(name):
