@@ -1091,15 +1091,18 @@ template void launch_conv3<f32s>(const ConvArgs&, int, int, int, int, hipStream_
 // (mobilenetv3.py:37,39; torchvision features[0]).  Normalisation is applied to in-bounds
 // pixels only, so the conv's zero padding pads the *normalised* image like the reference.
 // ------------------------------------------------------------------------------------------
+// Four threads per output pixel, four output channels each: 4x the waves of a thread-per-pixel layout on a
+// grid that is otherwise too small to fill the chip, and a quarter of the FMAs behind each thread's 9 loads.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv(StemArgs a) {
     [[maybe_unused]] Stamper stamp;
-    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    const int gid = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    const int p = gid >> 2, oq = gid & 3;
     if (p >= a.Ho * a.Wo) return;
     const int oy = p / a.Wo, ox = p - oy * a.Wo;
-    float acc[16];
+    float acc[4];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = a.bias[o];
+    for (int o = 0; o < 4; ++o) acc[o] = a.bias[oq * 4 + o];
     const T* xb = (const T*)a.s0 + (size_t)n * a.Hi * a.Wi * 4;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -1113,23 +1116,19 @@ __global__ __launch_bounds__(256) void stem_conv(StemArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xn = (v[c] - a.mean[c]) / a.std_[c];
-                const float* w = a.w + ((ky * 3 + kx) * 3 + c) * 16;
+                const f32x4 w = *(const f32x4*)(a.w + ((ky * 3 + kx) * 3 + c) * 16 + oq * 4);
 #pragma unroll
-                for (int o = 0; o < 16; ++o) acc[o] += xn * w[o];
+                for (int o = 0; o < 4; ++o) acc[o] += xn * w[o];
             }
         }
     }
-    T* yb = (T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 16;
+    f32x4 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_f(acc[q * 4 + r], ACT_HSWISH);
-        st4f(yb + q * 4, v);
-    }
+    for (int r = 0; r < 4; ++r) v[r] = act_f(acc[r], ACT_HSWISH);
+    st4f((T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 16 + oq * 4, v);
 }
 template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((stem_conv<T>), dim3((a.Ho * a.Wo + 255) / 256, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_conv<T>), dim3((a.Ho * a.Wo * 4 + 255) / 256, N), dim3(256), 0, s, a);
 }
 template void launch_stem<f16>(const StemArgs&, int, hipStream_t);
 template void launch_stem<float>(const StemArgs&, int, hipStream_t);
@@ -1139,49 +1138,70 @@ template void launch_stem<float>(const StemArgs&, int, hipStream_t);
 // bilinear coordinates (model/model.py:80-81: align_corners=False,
 // recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
 // ------------------------------------------------------------------------------------------
-// One thread produces a 2x2 block of s0 and the s1 pixel above it (first level of the decoder's
-// AvgPool pyramid, decoder.py:33-36: 2x2, ceil_mode, count_include_pad=False).
+// Four adjacent lanes produce the 2x2 block of s0 under one s1 pixel (one s0 pixel each: 12 source taps, one round
+// trip to memory) and exchange their results through DPP for the first level of the decoder's AvgPool pyramid
+// (decoder.py:33-36: 2x2, ceil_mode, count_include_pad=False), summed in the fixed order (0,0) (0,1) (1,0) (1,1).
+__device__ __forceinline__ float quad_lane(float v, int k) {        // value of lane k of this lane's group of 4
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    switch (k) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, i, 0x00, 0xf, 0xf, true); break;      // quad_perm [0,0,0,0]
+        case 1: r = __builtin_amdgcn_update_dpp(0, i, 0x55, 0xf, 0xf, true); break;      // [1,1,1,1]
+        case 2: r = __builtin_amdgcn_update_dpp(0, i, 0xaa, 0xf, 0xf, true); break;      // [2,2,2,2]
+        default: r = __builtin_amdgcn_update_dpp(0, i, 0xff, 0xf, 0xf, true); break;     // [3,3,3,3]
+    }
+    return __builtin_bit_cast(float, r);
+}
 template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
-    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (p >= a.h1 * a.w1) return;
+    const int gid = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    const int p = min(gid >> 2, a.h1 * a.w1 - 1), k = gid & 3;       // clamped: every lane of a quad stays for the exchange
+    const bool live = (gid >> 2) < a.h1 * a.w1;
     const int py = p / a.w1, px = p - py * a.w1;
     const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * a.H * a.W;
     const size_t plane = (size_t)a.H * a.W;
-    f32x4 acc = f32x4{0, 0, 0, 0};
-    int cnt = 0;
+    const int oy = 2 * py + (k >> 1), ox = 2 * px + (k & 1);
+    const bool inb = oy < a.h && ox < a.w;
+    f32x4 o = f32x4{0, 0, 0, 0};
+    {
+        const int cy = min(oy, a.h - 1), cx = min(ox, a.w - 1);
+        float sy = a.scale_y * (cy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = a.scale_x * (cx + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        int y0 = (int)sy, x0 = (int)sx;
+        if (y0 > a.H - 1) y0 = a.H - 1;
+        if (x0 > a.W - 1) x0 = a.W - 1;
+        const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
+        const float ly = sy - y0, lx = sx - x0;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int oy = 2 * py + dy, ox = 2 * px + dx;
-            if (oy >= a.h || ox >= a.w) continue;
-            float sy = a.scale_y * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-            float sx = a.scale_x * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-            int y0 = (int)sy, x0 = (int)sx;
-            if (y0 > a.H - 1) y0 = a.H - 1;
-            if (x0 > a.W - 1) x0 = a.W - 1;
-            const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
-            const float ly = sy - y0, lx = sx - x0;
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const TIO* pl = sp + c * plane;
-                const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
-                const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
-                o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-                o[c] = (float)(T)o[c];
-            }
-            o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
-            st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
-            acc += o; ++cnt;
+        for (int c = 0; c < 3; ++c) {
+            const TIO* pl = sp + c * plane;
+            const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
+            const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
+            o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            o[c] = (float)(T)o[c];
         }
-    acc = acc / (float)cnt;
-    st4f((T*)a.s1 + ((size_t)n * a.h1 * a.w1 + p) * 4, acc);
+        o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
+    }
+    if (live && inb) st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
+    // s1: mean of the valid pixels of the quad
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    const float fin = inb ? 1.f : 0.f;
+    float cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float vj = quad_lane(fin, j);
+        cnt += vj;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float t = quad_lane(o[c], j); if (vj != 0.f) acc[c] += t; }
+    }
+    if (live && k == 0) {
+        acc = acc / cnt;
+        st4f((T*)a.s1 + ((size_t)n * a.h1 * a.w1 + p) * 4, acc);
+    }
 }
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
-    const dim3 grid((a.h1 * a.w1 + 255) / 256, N);
+    const dim3 grid((a.h1 * a.w1 * 4 + 255) / 256, N);
     if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((downsample<T, T>), grid, dim3(256), 0, s, a);
 }
