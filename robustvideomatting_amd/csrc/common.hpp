@@ -107,8 +107,10 @@ struct StemArgs {
 };
 
 // ---- resize / pyramid ----------------------------------------------------------------------
-struct DownArgs { const void* src; void* s0; void* s1; int H, W, h, w, h1, w1; float scale_y, scale_x; };
-struct PoolArgs { const void* s1; void* s2; void* s3; int H1, W1, H2, W2, H3, W3; };
+struct DownArgs {
+    const void* src; void* s0; void* s1; void* s2; void* s3;
+    int H, W, h, w, h1, w1, h2, w2, h3, w3; float scale_y, scale_x;
+};
 
 struct MaxPoolArgs { const void* x; void* y; int C, Hi, Wi, Ho, Wo; };
 
@@ -158,7 +160,6 @@ template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW
 template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s);
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s);
-template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);

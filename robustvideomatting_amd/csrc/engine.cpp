@@ -665,16 +665,14 @@ int build_plan(rvm_ctx* c) {
     T* s[4];
     for (int l = 0; l < 4; ++l) s[l] = abuf((size_t)B * lh[l] * lw[l] * 4);
     {
-        DownArgs a; a.s0 = s[0]; a.s1 = s[1]; a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w; a.h1 = lh[1]; a.w1 = lw[1];
+        DownArgs a; a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2]; a.s3 = s[3];
+        a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w; a.h1 = lh[1]; a.w1 = lw[1]; a.h2 = lh[2]; a.w2 = lw[2]; a.h3 = lh[3]; a.w3 = lw[3];
         a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
-        // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0, s1 writes
+        // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0..s3 writes
         const double taps = (c->ds == 1.0) ? 1.0 : 4.0;
-        add("downsample_s0s1", 8.0 * B * c->h * c->w * 3, (double)B * c->h * c->w * (3 * taps * ies + 5 * es),
+        const double pyr = (double)(lh[1] * lw[1] + lh[2] * lw[2] + lh[3] * lw[3]);
+        add("downsample_pyramid", 8.0 * B * c->h * c->w * 3 + 8.0 * B * pyr, (double)B * (c->h * c->w * (3 * taps * ies + 4 * es) + pyr * 4 * es),
             [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); });
-        PoolArgs p; p.s1 = s[1]; p.s2 = s[2]; p.s3 = s[3];
-        p.H1 = lh[1]; p.W1 = lw[1]; p.H2 = lh[2]; p.W2 = lw[2]; p.H3 = lh[3]; p.W3 = lw[3];
-        add("pyramid_s2s3", 8.0 * B * lh[1] * lw[1], (double)B * (lh[1] * lw[1] + lh[2] * lw[2] + lh[3] * lw[3]) * 4 * es,
-            [=](hipStream_t st, const FrameIO&) { launch_pool<T>(p, B, st); });
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 

@@ -1138,9 +1138,11 @@ template void launch_stem<float>(const StemArgs&, int, hipStream_t);
 // bilinear coordinates (model/model.py:80-81: align_corners=False,
 // recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
 // ------------------------------------------------------------------------------------------
-// Four adjacent lanes produce the 2x2 block of s0 under one s1 pixel (one s0 pixel each: 12 source taps, one round
-// trip to memory) and exchange their results through DPP for the first level of the decoder's AvgPool pyramid
-// (decoder.py:33-36: 2x2, ceil_mode, count_include_pad=False), summed in the fixed order (0,0) (0,1) (1,0) (1,1).
+// One wave = one 8x8 block of s0 = one s3 pixel, lanes in Morton order: 4 adjacent lanes are the 2x2 block under one
+// s1 pixel, 16 the 4x4 block under one s2 pixel.  Every lane interpolates ONE s0 pixel (12 source taps, one round
+// trip to memory); the three levels of the decoder's AvgPool pyramid (decoder.py:33-39: 2x2, ceil_mode,
+// count_include_pad=False) are then formed in registers through DPP / bpermute / readlane, each level from the
+// previous one rounded to the storage type, children summed in the order (0,0) (0,1) (1,0) (1,1).
 __device__ __forceinline__ float quad_lane(float v, int k) {        // value of lane k of this lane's group of 4
     const int i = __builtin_bit_cast(int, v);
     int r;
@@ -1155,15 +1157,16 @@ __device__ __forceinline__ float quad_lane(float v, int k) {        // value of 
 template <typename T, typename TIO>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
-    const int gid = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    const int p = min(gid >> 2, a.h1 * a.w1 - 1), k = gid & 3;       // clamped: every lane of a quad stays for the exchange
-    const bool live = (gid >> 2) < a.h1 * a.w1;
-    const int py = p / a.w1, px = p - py * a.w1;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, n = blockIdx.y;
+    if (wv >= a.h3 * a.w3) return;                                   // whole wave
+    const int y3 = wv / a.w3, x3 = wv - y3 * a.w3;
+    const int dx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    const int dy = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int oy = 8 * y3 + dy, ox = 8 * x3 + dx;
+    const bool inb = oy < a.h && ox < a.w;
     const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * a.H * a.W;
     const size_t plane = (size_t)a.H * a.W;
-    const int oy = 2 * py + (k >> 1), ox = 2 * px + (k & 1);
-    const bool inb = oy < a.h && ox < a.w;
-    f32x4 o = f32x4{0, 0, 0, 0};
+    f32x4 o;
     {
         const int cy = min(oy, a.h - 1), cx = min(ox, a.w - 1);
         float sy = a.scale_y * (cy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
@@ -1183,80 +1186,73 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         }
         o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
     }
-    if (live && inb) st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
-    // s1: mean of the valid pixels of the quad
-    f32x4 acc = f32x4{0, 0, 0, 0};
-    const float fin = inb ? 1.f : 0.f;
-    float cnt = 0.f;
+    if (inb) st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
+    // ---- s1: the quad's valid pixels
+    f32x4 v1 = f32x4{0, 0, 0, 0};
+    float c1 = 0.f;
+    {
+        const float fin = inb ? 1.f : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float vj = quad_lane(fin, j);
-        cnt += vj;
+        for (int j = 0; j < 4; ++j) {
+            const float vj = quad_lane(fin, j);
+            c1 += vj;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float t = quad_lane(o[c], j); if (vj != 0.f) acc[c] += t; }
+            for (int c = 0; c < 4; ++c) { const float t = quad_lane(o[c], j); if (vj != 0.f) v1[c] += t; }
+        }
     }
-    if (live && k == 0) {
-        acc = acc / cnt;
-        st4f((T*)a.s1 + ((size_t)n * a.h1 * a.w1 + p) * 4, acc);
+    const bool ex1 = c1 > 0.f;
+    if (ex1) {
+        v1 = v1 / c1;
+        if ((lane & 3) == 0) st4f((T*)a.s1 + (((size_t)n * a.h1 + (oy >> 1)) * a.w1 + (ox >> 1)) * 4, v1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v1[c] = (float)(T)v1[c];         // the next level averages what was stored
+    }
+    // ---- s2: the four s1 pixels of this 16-lane group (lanes base, base+4, base+8, base+12)
+    f32x4 v2 = f32x4{0, 0, 0, 0};
+    float c2 = 0.f;
+    {
+        const float f1 = ex1 ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int srcl = (lane & 48) + 4 * j;
+            const float vj = __shfl(f1, srcl);
+            c2 += vj;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = __shfl(v1[c], srcl); if (vj != 0.f) v2[c] += t; }
+        }
+    }
+    const bool ex2 = c2 > 0.f;
+    if (ex2) {
+        v2 = v2 / c2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v2[c] = (float)(T)v2[c];
+        if ((lane & 15) == 0) st4f((T*)a.s2 + (((size_t)n * a.h2 + (oy >> 2)) * a.w2 + (ox >> 2)) * 4, v2);
+    }
+    // ---- s3: the four s2 pixels of the wave (lanes 0, 16, 32, 48)
+    f32x4 v3 = f32x4{0, 0, 0, 0};
+    float c3 = 0.f;
+    {
+        const float f2 = ex2 ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float vj = __shfl(f2, 16 * j);
+            c3 += vj;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = __shfl(v2[c], 16 * j); if (vj != 0.f) v3[c] += t; }
+        }
+    }
+    if (lane == 0) {
+        v3 = v3 / c3;
+        st4f((T*)a.s3 + (((size_t)n * a.h3 + y3) * a.w3 + x3) * 4, v3);
     }
 }
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
-    const dim3 grid((a.h1 * a.w1 * 4 + 255) / 256, N);
+    const dim3 grid((a.h3 * a.w3 + 3) / 4, N);
     if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((downsample<T, T>), grid, dim3(256), 0, s, a);
 }
 template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
 template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
-
-// Levels 2 and 3 of the pyramid in one launch: a thread owns one s3 pixel, averages the (up to)
-// 4x4 s1 pixels under it into 2x2 s2 pixels, stores them, and averages those into s3.
-template <typename T>
-__global__ __launch_bounds__(256) void pyramid23(PoolArgs a) {
-    [[maybe_unused]] Stamper stamp;
-    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (p >= a.H3 * a.W3) return;
-    const int y3 = p / a.W3, x3 = p - y3 * a.W3;
-    const T* s1 = (const T*)a.s1 + (size_t)n * a.H1 * a.W1 * 4;
-    // the (up to) 4 x 4 s1 pixels are requested first (clamped coordinates): one round trip
-    f32x4 px1[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = min(4 * y3 + j, a.H1 - 1), ix = min(4 * x3 + i, a.W1 - 1);
-            px1[j][i] = ld4f(s1 + ((size_t)iy * a.W1 + ix) * 4);
-        }
-    f32x4 acc3 = f32x4{0, 0, 0, 0};
-    int cnt3 = 0;
-#pragma unroll
-    for (int ey = 0; ey < 2; ++ey)
-#pragma unroll
-        for (int ex = 0; ex < 2; ++ex) {
-            const int y2 = 2 * y3 + ey, x2 = 2 * x3 + ex;
-            if (y2 >= a.H2 || x2 >= a.W2) continue;
-            f32x4 acc = f32x4{0, 0, 0, 0};
-            int cnt = 0;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int iy = 2 * y2 + dy, ix = 2 * x2 + dx;
-                    if (iy < a.H1 && ix < a.W1) { acc += px1[2 * ey + dy][2 * ex + dx]; ++cnt; }
-                }
-            acc = acc / (float)cnt;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = (float)(T)acc[c];
-            st4f((T*)a.s2 + (((size_t)n * a.H2 + y2) * a.W2 + x2) * 4, acc);
-            acc3 += acc; ++cnt3;
-        }
-    acc3 = acc3 / (float)cnt3;
-    st4f((T*)a.s3 + ((size_t)n * a.H3 * a.W3 + p) * 4, acc3);
-}
-template <typename T> void launch_pool(const PoolArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((pyramid23<T>), dim3((a.H3 * a.W3 + 255) / 256, N), dim3(256), 0, s, a);
-}
-template void launch_pool<f16>(const PoolArgs&, int, hipStream_t);
-template void launch_pool<float>(const PoolArgs&, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Refiner, low-res half: project_mat 1x1 (model.py:62) + guided-filter statistics with the
