@@ -708,19 +708,35 @@ int build_plan(rvm_ctx* c) {
         const int geo = L.geo;
         if (geo == 0 && L.nchunks == 1) {
             // pick the (MW, NW) tile that minimises blocks-per-CU x time-per-block (ties: the larger tile, less halo)
-            const int cand[5][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
-            int valid[5], nvalid = 0, model = -1;
+            // candidate 5 = conv_sk, the split-K direct form for small maps (MW = 0): direct 8-channel-aligned sources only
+            const int cand[6][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}, {0, epi == EPI_GRU_IH ? 2 : 1}};
+            bool sk_ok = true;
+            {
+                ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
+                fill(probe, none);
+                if (probe.nsrc < 1 || probe.nsrc > 2) sk_ok = false;
+                for (int k = 0; k < probe.nsrc && k < 2; ++k) if (probe.src[k].up || probe.src[k].C % 8) sk_ok = false;
+            }
+            int valid[6], nvalid = 0, model = -1;
             double best = 1e30;
-            for (int k = 0; k < 5; ++k) {
+            for (int k = 0; k < 6; ++k) {
                 const int m = cand[k][0], nw = cand[k][1];
-                if (epi == EPI_GRU_IH && nw != 2) continue;
-                const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC, SK0);
-                if (lds > 150 * 1024) continue;
-                // measured on the HD frame (every candidate of the 13 decoder convs timed alone): a block takes about
-                // 2.7 us + 0.128 us per (K step x 16x16 output tile), and the blocks that share a CU take turns
-                // (they are bound by what one CU can pull from L2), so the launch costs that times the blocks per CU
-                const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
-                const double cost = (double)cdiv(blocks, 256) * (2.7 + 0.128 * L.KS * m * nw);
+                double cost;
+                if (m == 0) {
+                    if (!sk_ok) continue;
+                    // measured (17x30 and 34x60 ConvGRUs): about 3.2 us + 0.055 us per K step and n-tile of a block
+                    const int blocks = a.tiles_x * Ho * cdiv(L.NT, nw) * B;
+                    cost = (double)cdiv(blocks, 512) * (3.2 + 0.055 * L.KS * nw);
+                } else {
+                    if (epi == EPI_GRU_IH && nw != 2) continue;
+                    const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC, SK0);
+                    if (lds > 150 * 1024) continue;
+                    // measured on the HD frame (every candidate of the 13 decoder convs timed alone): a block takes about
+                    // 2.7 us + 0.128 us per (K step x 16x16 output tile), and the blocks that share a CU take turns
+                    // (they are bound by what one CU can pull from L2), so the launch costs that times the blocks per CU
+                    const int blocks = a.tiles_x * cdiv(Ho, 4 * m) * cdiv(L.NT, nw) * B;
+                    cost = (double)cdiv(blocks, 256) * (2.7 + 0.128 * L.KS * m * nw);
+                }
                 if (cost < best - 1e-9) { best = cost; model = nvalid; }
                 valid[nvalid++] = k;
             }
@@ -738,7 +754,8 @@ int build_plan(rvm_ctx* c) {
         if (SK0 * NW * 512 * (int)sizeof(T) < 16 * 512) SK0 = 8;                   // fp16, one n-tile
         if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");
         a.SK = SK0;
-        {
+        if (MW == 0) { a.SK = 8; a.SKlog2 = 3; }                // conv_sk: no weight stages
+        else {
             const int blocks = a.tiles_x * cdiv(Ho, 4 * MW) * cdiv(L.NT, NW) * B;
             const size_t budget = blocks <= 256 ? 150 * 1024 : (blocks <= 512 ? 78 * 1024 : 52 * 1024);
             const char* e = getenv("RVM_CONV_SK");

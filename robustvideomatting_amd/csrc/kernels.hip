@@ -1072,7 +1072,162 @@ static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
     hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(CONV_NT), conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.SK), s, a);
 }
 // geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
+// ------------------------------------------------------------------------------------------
+// 3x3 conv (pad 1, stride 1) for SMALL maps: the same implicit GEMM as conv_kxk, but shaped like the split-K
+// pw_gemm - a block owns ONE 16-pixel row segment x NW n-tiles, its 4 waves take every 4th K step, operands come
+// straight from L2 into registers (4 K steps of prefetch, no LDS staging, no barriers in the K loop) and the four
+// partial accumulators are added through LDS in a fixed order.  On the 17x30 / 34x60 ConvGRUs conv_kxk has only
+// 40..108 blocks, each streaming its ~150 KB of weights through one CU at the ~30 GB/s a barrier-paced stage
+// pipeline reaches; this form spreads the same stream over 3-4x as many CUs.  Sources are direct (not upsampled)
+// and 8-channel aligned; fp16 state tensors feed the split MFMA as (hi = value, lo = 0).
+// ------------------------------------------------------------------------------------------
+template <typename T> struct SkOperand;                              // one 8-channel K group of one pixel, as loaded
+template <> struct SkOperand<f16> {
+    f32x4 a; bool ok;
+    __device__ __forceinline__ void load(const void* p, bool) { a = *(const f32x4*)p; }
+    __device__ __forceinline__ Frag<f16> frag(bool) const { Frag<f16> f; f.v = __builtin_bit_cast(f16x8, a); if (!ok) f.zero(); return f; }
+};
+template <> struct SkOperand<float> {
+    f32x4 a, b; bool ok;
+    __device__ __forceinline__ void load(const void* p, bool half) { a = *(const f32x4*)p; b = *(const f32x4*)((const char*)p + (half ? 0 : 16)); }
+    __device__ __forceinline__ Frag<float> frag(bool half) const {
+        Frag<float> f;
+        if (half) { const f16x8 h = __builtin_bit_cast(f16x8, a); f.lo = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; f.hi = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}; }
+        else { f.lo = a; f.hi = b; }
+        if (!ok) f.zero();
+        return f;
+    }
+};
+template <> struct SkOperand<f32s> {
+    f32x4 a, b; bool ok;
+    __device__ __forceinline__ void load(const void* p, bool half) { a = *(const f32x4*)p; b = *(const f32x4*)((const char*)p + (half ? 0 : 16)); }
+    __device__ __forceinline__ Frag<f32s> frag(bool half) const {
+        Frag<f32s> f;
+        if (half) { f.hi = __builtin_bit_cast(f16x8, a); f.lo = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }     // an fp16 value is its own hi part
+        else f.set(a, b);
+        if (!ok) f.zero();
+        return f;
+    }
+};
+template <typename T, int NW>
+__global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
+    [[maybe_unused]] Stamper stamp;
+    __shared__ f32x4 red[4][NW][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int tx = blockIdx.x % a.tiles_x, y = blockIdx.x / a.tiles_x, n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int px = tx * 16 + l15;
+    const int nt0 = blockIdx.y * NW;
+    bool nv[NW];
+    const T* wp[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        nv[ni] = (nt0 + ni) < a.NT;
+        wp[ni] = (const T*)a.w + (size_t)(nv[ni] ? nt0 + ni : nt0) * a.KS * 512;
+    }
+    const int NQ8 = a.Cpad >> 3;
+    const unsigned invQ = 0xFFFFFFFFu / (unsigned)NQ8 + 1u;          // q8 / NQ8 == umulhi(q8, invQ) for these sizes
+    const int C0 = a.src[0].C, Ctot = C0 + (a.nsrc > 1 ? a.src[1].C : 0);
+    const bool kernel16 = sizeof(T) == 2;
+    constexpr int PF = 4;
+    Frag<T> wf[PF][NW];
+    SkOperand<T> xo[PF];
+    bool xh[PF];
+    auto load_step = [&](int ks, Frag<T>* wo, SkOperand<T>& x, bool& half) {
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) wo[ni].loadw(wp[ni] + (size_t)ks * 512, lane);
+        const int q8 = ks * 4 + g;
+        const int tap = (int)__umulhi((unsigned)q8, invQ), c = (q8 - tap * NQ8) * 8;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int yy = y + dy - 1, xx = px + dx - 1;
+        const bool second = c >= C0;
+        const ConvSrc& S = second ? a.src[1] : a.src[0];
+        half = kernel16 || S.f16;
+        x.ok = tap < 9 && c < Ctot && yy >= 0 && yy < H && xx >= 0 && xx < W && S.p != nullptr;
+        const size_t off = x.ok ? (((size_t)n * H + yy) * W + xx) * S.Cs + (c - (second ? C0 : 0)) : 0;
+        const void* base = S.p ? S.p : a.src[0].p;                   // a missing state (first frame) reads as zeros
+        x.load((const char*)base + off * (half ? 2 : 4), half);
+    };
+    f32x4 acc[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) acc[ni] = f32x4{0, 0, 0, 0};
+    const int nst = (a.KS - wave + 3) / 4;                           // this wave's K steps: wave, wave + 4, ...
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_step(min(wave + 4 * p, a.KS - 1), wf[p], xo[p], xh[p]);
+    for (int j0 = 0; j0 < nst; j0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int j = j0 + p;
+            if (j < nst) {
+                const Frag<T> xa = xo[p].frag(xh[p]);
+#pragma unroll
+                for (int ni = 0; ni < NW; ++ni) mma(acc[ni], wf[p][ni], xa);
+                if (j + PF < nst) load_step(wave + 4 * (j + PF), wf[p], xo[p], xh[p]);
+            }
+        }
+    }
+    stamp(1);
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) red[wave][ni][lane] = acc[ni];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) acc[ni] = (red[0][ni][lane] + red[1][ni][lane]) + (red[2][ni][lane] + red[3][ni][lane]);
+
+    // ---- epilogue (wave 0): lane holds channels g*4..g*4+3 of pixel px for every n-tile; same arithmetic as conv_kxk
+    if (px >= W) return;
+    const size_t pix = ((size_t)n * H + y) * W + px;
+    const bool s16 = sizeof(T) == 2 || a.state16;
+    if (a.epi == EPI_RELU) {
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const int ch = (nt0 + ni) * 16 + g * 4;
+            if (!nv[ni] || ch >= a.Cout) continue;
+            f32x4 v = acc[ni] + *(const f32x4*)(a.bias + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            st4f((T*)a.y + pix * a.ys + ch, v);
+        }
+    } else if (a.epi == EPI_GRU_IH) {
+        if constexpr (NW >= 2) {
+#pragma unroll
+            for (int ni = 0; ni + 1 < NW; ni += 2) {
+                const int t = nt0 + ni;
+                const int c = (t >> 1) * 16 + g * 4;
+                if (!nv[ni] || c >= a.hC) continue;
+                f32x4 rv = acc[ni] + *(const f32x4*)(a.bias + t * 16 + g * 4);
+                f32x4 zv = acc[ni + 1] + *(const f32x4*)(a.bias + (t + 1) * 16 + g * 4);
+                f32x4 h = f32x4{0, 0, 0, 0};
+                if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, s16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rv[r] = sigmoid_f(rv[r]) * h[r]; zv[r] = sigmoid_f(zv[r]); }
+                st4f((T*)a.rh + pix * a.hC + c, rv);
+                *(f32x4*)(a.z + pix * a.hC + c) = zv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const int c = (nt0 + ni) * 16 + g * 4;
+            if (!nv[ni] || c >= a.hC) continue;
+            f32x4 cv = acc[ni] + *(const f32x4*)(a.bias + c);
+            f32x4 h = f32x4{0, 0, 0, 0};
+            if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, s16);
+            const f32x4 z = *(const f32x4*)(a.z + pix * a.hC + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
+            st4x(a.hout, pix * a.hC + c, s16, cv);
+            if (a.hout2) st4x(a.hout2, pix * a.hC + c, s16, cv);
+        }
+    }
+    stamp(2);
+}
+template <typename T, int NW> static void launch_conv_sk(const ConvArgs& a, int N, hipStream_t s) {
+    dim3 grid(a.tiles_x * a.H, (a.NT + NW - 1) / NW, N);
+    hipLaunchKernelGGL((conv_sk<T, NW>), grid, dim3(256), 0, s, a);
+}
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
+    if (MW == 0) { if (NW == 2) launch_conv_sk<T, 2>(a, N, s); else launch_conv_sk<T, 1>(a, N, s); return; }   // small-map form
     if (geo == 1) { launch_conv_t<T, 1, 2, 3, 2, 1>(a, N, s); return; }
     if (geo == 2) { launch_conv_t<T, 1, 2, 3, 1, 2>(a, N, s); return; }
     if (geo == 3) { launch_conv_t<T, 1, 2, 7, 2, 1>(a, N, s); return; }
