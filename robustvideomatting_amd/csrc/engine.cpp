@@ -708,14 +708,14 @@ int build_plan(rvm_ctx* c) {
         const int geo = L.geo;
         if (geo == 0 && L.nchunks == 1) {
             // pick the (MW, NW) tile that minimises blocks-per-CU x time-per-block (ties: the larger tile, less halo)
-            // candidate 5 = conv_sk, the split-K direct form for small maps (MW = 0): direct 8-channel-aligned sources only
+            // candidate 5 = conv_sk, the split-K direct form for small maps (MW = 0): direct (not upsampled) sources only
             const int cand[6][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}, {0, epi == EPI_GRU_IH ? 2 : 1}};
             bool sk_ok = true;
             {
                 ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
                 fill(probe, none);
                 if (probe.nsrc < 1 || probe.nsrc > 2) sk_ok = false;
-                for (int k = 0; k < probe.nsrc && k < 2; ++k) if (probe.src[k].up || probe.src[k].C % 8) sk_ok = false;
+                for (int k = 0; k < probe.nsrc && k < 2; ++k) if (probe.src[k].up || probe.src[k].C % 4) sk_ok = false;
             }
             int valid[6], nvalid = 0, model = -1;
             double best = 1e30;

@@ -1109,7 +1109,30 @@ template <> struct SkOperand<f32s> {
         return f;
     }
 };
-template <typename T, int NW>
+// The same operand fetched as two 4-channel halves, each from the source that holds it: for concatenations whose
+// channel counts are multiples of 4 but not of 8 (the 20-channel ConvGRU: x[16..19] | h[0..3] share a K group).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct SkQuads {
+    f32x4 q[2]; bool ok[2], half[2];
+    __device__ __forceinline__ void load(int i, const void* p, bool h) {
+        half[i] = h;
+        if (h) { const f32x2 t = *(const f32x2*)p; q[i] = f32x4{t[0], t[1], 0.f, 0.f}; }
+        else q[i] = *(const f32x4*)p;
+    }
+    __device__ __forceinline__ f32x4 value(int i) const {
+        f32x4 v = q[i];
+        if (half[i]) { const f16x4 h = __builtin_bit_cast(f16x4, f32x2{q[i][0], q[i][1]}); v = __builtin_convertvector(h, f32x4); }
+        return ok[i] ? v : f32x4{0, 0, 0, 0};
+    }
+    __device__ __forceinline__ Frag<T> frag() const;
+};
+template <> __device__ __forceinline__ Frag<f32s> SkQuads<f32s>::frag() const { Frag<f32s> f; f.set(value(0), value(1)); return f; }
+template <> __device__ __forceinline__ Frag<float> SkQuads<float>::frag() const { Frag<float> f; f.lo = value(0); f.hi = value(1); return f; }
+template <> __device__ __forceinline__ Frag<f16> SkQuads<f16>::frag() const {
+    const f16x4 a = __builtin_convertvector(value(0), f16x4), b = __builtin_convertvector(value(1), f16x4);
+    Frag<f16> f; f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); return f;
+}
+template <typename T, int NW, bool QUAD>
 __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     [[maybe_unused]] Stamper stamp;
     __shared__ f32x4 red[4][NW][64];
@@ -1132,37 +1155,56 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     constexpr int PF = 4;
     Frag<T> wf[PF][NW];
     SkOperand<T> xo[PF];
+    SkQuads<T> xq[PF];
     bool xh[PF];
-    auto load_step = [&](int ks, Frag<T>* wo, SkOperand<T>& x, bool& half) {
+    auto load_step = [&](int ks, int p) {
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) wo[ni].loadw(wp[ni] + (size_t)ks * 512, lane);
+        for (int ni = 0; ni < NW; ++ni) wf[p][ni].loadw(wp[ni] + (size_t)ks * 512, lane);
         const int q8 = ks * 4 + g;
         const int tap = (int)__umulhi((unsigned)q8, invQ), c = (q8 - tap * NQ8) * 8;
         const int dy = tap / 3, dx = tap - dy * 3;
         const int yy = y + dy - 1, xx = px + dx - 1;
-        const bool second = c >= C0;
-        const ConvSrc& S = second ? a.src[1] : a.src[0];
-        half = kernel16 || S.f16;
-        x.ok = tap < 9 && c < Ctot && yy >= 0 && yy < H && xx >= 0 && xx < W && S.p != nullptr;
-        const size_t off = x.ok ? (((size_t)n * H + yy) * W + xx) * S.Cs + (c - (second ? C0 : 0)) : 0;
-        const void* base = S.p ? S.p : a.src[0].p;                   // a missing state (first frame) reads as zeros
-        x.load((const char*)base + off * (half ? 2 : 4), half);
+        const bool pos = tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t pixel = pos ? ((size_t)n * H + yy) * W + xx : 0;
+        if constexpr (!QUAD) {
+            const bool second = c >= C0;
+            const ConvSrc& S = second ? a.src[1] : a.src[0];
+            const bool half = kernel16 || S.f16;
+            xh[p] = half;
+            xo[p].ok = pos && c < Ctot && S.p != nullptr;
+            const size_t off = xo[p].ok ? pixel * S.Cs + (c - (second ? C0 : 0)) : 0;
+            const void* base = S.p ? S.p : a.src[0].p;               // a missing state (first frame) reads as zeros
+            xo[p].load((const char*)base + off * (half ? 2 : 4), half);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int cq = c + 4 * i;
+                const bool second = cq >= C0;
+                const ConvSrc& S = second ? a.src[1] : a.src[0];
+                const bool half = kernel16 || S.f16;
+                xq[p].ok[i] = pos && cq < Ctot && S.p != nullptr;
+                const size_t off = xq[p].ok[i] ? pixel * S.Cs + (cq - (second ? C0 : 0)) : 0;
+                const void* base = S.p ? S.p : a.src[0].p;
+                xq[p].load(i, (const char*)base + off * (half ? 2 : 4), half);
+            }
+        }
     };
     f32x4 acc[NW];
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) acc[ni] = f32x4{0, 0, 0, 0};
     const int nst = (a.KS - wave + 3) / 4;                           // this wave's K steps: wave, wave + 4, ...
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load_step(min(wave + 4 * p, a.KS - 1), wf[p], xo[p], xh[p]);
+    for (int p = 0; p < PF; ++p) load_step(min(wave + 4 * p, a.KS - 1), p);
     for (int j0 = 0; j0 < nst; j0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int j = j0 + p;
             if (j < nst) {
-                const Frag<T> xa = xo[p].frag(xh[p]);
+                Frag<T> xa;
+                if constexpr (QUAD) xa = xq[p].frag(); else xa = xo[p].frag(xh[p]);
 #pragma unroll
                 for (int ni = 0; ni < NW; ++ni) mma(acc[ni], wf[p][ni], xa);
-                if (j + PF < nst) load_step(wave + 4 * (j + PF), wf[p], xo[p], xh[p]);
+                if (j + PF < nst) load_step(wave + 4 * (j + PF), p);
             }
         }
     }
@@ -1224,7 +1266,10 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
 }
 template <typename T, int NW> static void launch_conv_sk(const ConvArgs& a, int N, hipStream_t s) {
     dim3 grid(a.tiles_x * a.H, (a.NT + NW - 1) / NW, N);
-    hipLaunchKernelGGL((conv_sk<T, NW>), grid, dim3(256), 0, s, a);
+    bool quad = false;                                               // a source whose channel count is not a multiple of 8
+    for (int k = 0; k < a.nsrc; ++k) quad |= (a.src[k].C % 8) != 0;
+    if (quad) hipLaunchKernelGGL((conv_sk<T, NW, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_sk<T, NW, false>), grid, dim3(256), 0, s, a);
 }
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
     if (MW == 0) { if (NW == 2) launch_conv_sk<T, 2>(a, N, s); else launch_conv_sk<T, 1>(a, N, s); return; }   // small-map form
