@@ -725,8 +725,9 @@ int build_plan(rvm_ctx* c) {
                 if (m == 0) {
                     if (!sk_ok) continue;
                     // measured (17x30 and 34x60 ConvGRUs): about 3.2 us + 0.055 us per K step and n-tile of a block
+                    // ... and never less than its weight stream (every block reads its n-tiles' whole K) at ~4.5 TB/s of L2
                     const int blocks = a.tiles_x * Ho * cdiv(L.NT, nw) * B;
-                    cost = (double)cdiv(blocks, 512) * (3.2 + 0.055 * L.KS * nw);
+                    cost = std::max((double)cdiv(blocks, 512) * (3.2 + 0.055 * L.KS * nw), (double)blocks * L.KS * nw * 512 * es / 4.5e6);
                 } else {
                     if (epi == EPI_GRU_IH && nw != 2) continue;
                     const size_t lds = conv_lds_bytes<T>(m, nw, 3, 1, 1, L.CC, SK0);
@@ -746,6 +747,20 @@ int build_plan(rvm_ctx* c) {
         } else {
             NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
             if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
+            // 3x3 layers of this kind on small maps (resnet50 layer3 / layer4 at 1/16 scale) have conv_sk as the alternative
+            if (L.KD == 3 && epi == EPI_RELU) {
+                bool sk_ok = true;
+                ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
+                fill(probe, none);
+                if (probe.nsrc < 1 || probe.nsrc > 2) sk_ok = false;
+                for (int k = 0; k < probe.nsrc && k < 2; ++k) if (probe.src[k].up || probe.src[k].C % 4) sk_ok = false;
+                if (sk_ok) {
+                    const int bk = a.tiles_x * cdiv(Ho, 4) * cdiv(L.NT, 2) * B, bs = a.tiles_x * Ho * L.NT * B;
+                    const double ck = (double)cdiv(bk, 256) * (2.7 * L.nchunks + 0.128 * L.KS * 2);
+                    const double cs_ = std::max((double)cdiv(bs, 512) * (3.2 + 0.055 * L.KS), (double)bs * L.KS * 512 * es / 4.5e6);
+                    if (tune_pick(name, 2, cs_ < ck ? 1 : 0) == 1) { MW = 0; NW = 1; a.cs = (geo == 1) ? 2 : 1; a.cd = (geo == 2) ? 2 : 1; }
+                }
+            }
         }
         const int cS = (geo == 1 || geo == 3) ? 2 : 1, cD = geo == 2 ? 2 : 1;
         if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");

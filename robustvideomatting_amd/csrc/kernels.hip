@@ -1073,7 +1073,7 @@ static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
 }
 // geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
 // ------------------------------------------------------------------------------------------
-// 3x3 conv (pad 1, stride 1) for SMALL maps: the same implicit GEMM as conv_kxk, but shaped like the split-K
+// 3x3 conv (stride 1 or 2, dilation 1 or 2, padding = dilation) for SMALL maps: the same implicit GEMM as conv_kxk, but shaped like the split-K
 // pw_gemm - a block owns ONE 16-pixel row segment x NW n-tiles, its 4 waves take every 4th K step, operands come
 // straight from L2 into registers (4 K steps of prefetch, no LDS staging, no barriers in the K loop) and the four
 // partial accumulators are added through LDS in a fixed order.  On the 17x30 / 34x60 ConvGRUs conv_kxk has only
@@ -1152,6 +1152,8 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     const unsigned invQ = 0xFFFFFFFFu / (unsigned)NQ8 + 1u;          // q8 / NQ8 == umulhi(q8, invQ) for these sizes
     const int C0 = a.src[0].C, Ctot = C0 + (a.nsrc > 1 ? a.src[1].C : 0);
     const bool kernel16 = sizeof(T) == 2;
+    const int cS = a.cs > 1 ? a.cs : 1, cD = a.cd > 1 ? a.cd : 1;
+    const int KSc0 = ((9 * a.CC + 31) / 32 + 7) / 8 * 8;           // K steps of a full channel chunk (conv_kxk's packing)
     constexpr int PF = 4;
     Frag<T> wf[PF][NW];
     SkOperand<T> xo[PF];
@@ -1160,12 +1162,22 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     auto load_step = [&](int ks, int p) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) wf[p][ni].loadw(wp[ni] + (size_t)ks * 512, lane);
-        const int q8 = ks * 4 + g;
-        const int tap = (int)__umulhi((unsigned)q8, invQ), c = (q8 - tap * NQ8) * 8;
+        int tap, c;
+        if (a.nchunks <= 1) {
+            const int q8 = ks * 4 + g;
+            tap = (int)__umulhi((unsigned)q8, invQ); c = (q8 - tap * NQ8) * 8;
+        } else {
+            // weights packed for conv_kxk's channel chunks: [chunk][tap][channel of the chunk], every chunk padded to
+            // a multiple of 8 K steps (K steps beyond the 9 taps are zero there)
+            const int chunk = min(ks / KSc0, a.nchunks - 1), ksl = ks - chunk * KSc0;
+            const int nq = min(a.CC, a.Cpad - chunk * a.CC) >> 3;
+            const int q8 = ksl * 4 + g;
+            tap = q8 / nq; c = chunk * a.CC + (q8 - tap * nq) * 8;
+        }
         const int dy = tap / 3, dx = tap - dy * 3;
-        const int yy = y + dy - 1, xx = px + dx - 1;
-        const bool pos = tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t pixel = pos ? ((size_t)n * H + yy) * W + xx : 0;
+        const int yy = y * cS + (dy - 1) * cD, xx = px * cS + (dx - 1) * cD;      // padding = dilation
+        const bool pos = tap < 9 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
+        const size_t pixel = pos ? ((size_t)n * a.Hi + yy) * a.Wi + xx : 0;
         if constexpr (!QUAD) {
             const bool second = c >= C0;
             const ConvSrc& S = second ? a.src[1] : a.src[0];
