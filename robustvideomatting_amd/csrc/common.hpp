@@ -46,15 +46,6 @@ struct PwArgs {
     int sstride, sHi, sWi, sWo;             // sstride > 1: strided 1x1 (input HxW = sHi x sWi, output width sWo)
 };
 
-// ---- depthwise conv ----------------------------------------------------------------------
-struct DwArgs {
-    const void* x; void* y;
-    const float* w;                         // [K*K][C] (BN folded)
-    const float* bias;                      // [C]
-    float* pool;                            // [N][nblk][C] partial sums of the output or null
-    int C, Hi, Wi, Ho, Wo, stride, dil, pad, act, ppb, nblk;
-};
-
 // ---- fused expand (1x1, MFMA) -> depthwise k x k (LDS) [-> squeeze-excite fc1 partial] -----------
 struct EdArgs {
     const void* x; int Cin; int xs;         // block input [N][Hi*Wi][xs]
@@ -78,14 +69,14 @@ struct GemvArgs {
     const void* w;                          // T [O][I]
     const float* bias;                      // [O] or null
     void* y; int y_is_T;                    // [N][O] float or T
-    int I, O, act, opw;                     // opw = outputs per wave
+    int I, O, act;
 };
 
 // ---- 3x3 implicit-GEMM conv (decoder, ConvGRU) ----------------------------------------------
 struct ConvSrc { const void* p; int C; int Cs; int up; int Hs; int Ws; int f16; };   // f16: fp16 tensor feeding an fp32 kernel
 enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
 struct ConvArgs {
-    ConvSrc src[4]; int nsrc; int Cpad; int ql_log2;
+    ConvSrc src[4]; int nsrc; int Cpad;
     const void* w; int KS; int NT; const float* bias;
     int H, W, tiles_x, epi;                 // H, W: OUTPUT size
     int Hi, Wi;                             // input size of the direct (non-upsampled) sources

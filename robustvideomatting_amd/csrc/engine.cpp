@@ -887,7 +887,7 @@ int build_plan(rvm_ctx* c) {
                     g2.xin = hpart; g2.nparts = nparts; g2.part_stride = b.se.S; g2.xscale = 1.f / (float)npix;
                     g2.xbias = (const float*)(wb + b.se.b1); g2.xact = ACT_RELU;
                     g2.w = wb + b.se.w2; g2.bias = (const float*)(wb + b.se.b2); g2.y = sc; g2.y_is_T = 1;
-                    g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID; g2.opw = 4;
+                    g2.I = b.se.S; g2.O = exp; g2.act = ACT_HSIGMOID;
                     add("mb" + std::to_string(i + 1) + ".se_fc", 4.0 * B * exp * b.se.S, 2.0 * exp * b.se.S * es,
                         [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g2, B, st); });
                     scale = sc;
@@ -967,7 +967,7 @@ int build_plan(rvm_ctx* c) {
         GemvArgs g; memset(&g, 0, sizeof g);
         g.xin = f4pool; g.nparts = MT4; g.part_stride = pool_stride; g.xscale = 1.f / (float)HW4;
         g.w = wb + c->aspp2_w; g.bias = nullptr; g.y = gate; g.y_is_T = 0; g.I = c->enc_out; g.O = c->aspp_c;
-        g.act = ACT_SIGMOID; g.opw = 1;
+        g.act = ACT_SIGMOID;
         add("aspp2_gate", 2.0 * B * g.I * g.O, (double)g.I * g.O * es, [=](hipStream_t st, const FrameIO&) { launch_gemv<T>(g, B, st); });
     }
     const int AC = c->aspp_c;
