@@ -73,7 +73,11 @@ struct GemvArgs {
 };
 
 // ---- 3x3 implicit-GEMM conv (decoder, ConvGRU) ----------------------------------------------
-struct ConvSrc { const void* p; int C; int Cs; int up; int Hs; int Ws; int f16; };   // f16: fp16 tensor feeding an fp32 kernel
+struct ConvSrc {
+    const void* p; int C; int Cs; int up; int Hs; int Ws;
+    int f16;                                // fp16 tensor feeding an fp32 kernel
+    int w0, nw;                             // conv_kxk: the waves [w0, w0 + nw) of a block stage this source (set by the launcher)
+};
 enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
 struct ConvArgs {
     ConvSrc src[4]; int nsrc; int Cpad;

@@ -794,56 +794,109 @@ template size_t conv_lds_bytes<float>(int, int, int, int, int, int, int);
 template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int, int);
 
 // Stage channel quads [q_lo, q_lo+q_cnt) of one source of the concatenated conv input into the
-// LDS halo patch (origin gy0,gx0 in source-resolution coordinates).  The (pixel, quad) items are
-// walked as one flat index, several per thread per round, with a branch-free body (clamped
-// address + select): 8 (direct) or 16 (bilinear) independent loads are in flight per thread,
-// which is what hides the L2 / Infinity-Cache latency of these small tensors.
+// LDS halo patch (origin gy0,gx0 in source-resolution coordinates), by the `nthr` threads (whole waves)
+// the launcher gave this source; `tl` is the thread's index among them.  The sources of a block are
+// staged by different waves at the same time, so the patch costs the L2 round trips of its slowest wave
+// group instead of the sum over the sources.  Items are walked as one flat index, UN per thread per round,
+// with a branch-free body (clamped address + select), so 8 independent loads are in flight per thread.
+//   direct source:  item = (pixel, quad), 1 load.
+//   x2 bilinear (align_corners=False, decoder.py:74), patch with even PH, PW on an odd origin (3x3 stride-1
+//                   tiles: origin = even tile corner - 1): item = (2x2 output block, quad); the outputs
+//                   (2i+1, 2i+2) x (2j+1, 2j+2) interpolate between the SAME source pixels (i, i+1) x (j, j+1),
+//                   4 loads for 4 outputs.  Weights, clamps and zero padding as in the per-pixel form.
 template <typename T, bool UP, bool HF, int PH, int PW>
 __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo, int q_cnt, int dst_c, int CSL, int n,
-                                             int gy0, int gx0, int H, int W, int tid) {
-    constexpr int UN = UP ? 2 : 4;                         // x 512 threads: as many loads in flight per CU as 4 / 8 x 256
+                                             int gy0, int gx0, int H, int W, int tl, int nthr) {
     const int QN = q_cnt;
     const unsigned inv = 0xFFFFFFFFu / (unsigned)QN + 1u;   // it / QN == umulhi(it, inv) for it < 2^16 .. see below
-    const int total = PH * PW * QN;
     constexpr bool hf = HF;                                  // compile-time: keeps the loads of a round branch-free
     const bool live = S.p != nullptr;
     if (!live) {                                             // no state yet (first frame): zeros
-        for (int it = tid; it < total; it += CONV_NT) {
+        const int total = PH * PW * QN;
+        for (int it = tl; it < total; it += nthr) {
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
             stp4(patch + pp * CSL, dst_c + q * 4, f32x4{0, 0, 0, 0});
         }
         return;
     }
     const void* base = S.p;
-    for (int it0 = tid; it0 < total; it0 += CONV_NT * UN) {
+    if constexpr (UP && PH % 2 == 0 && PW % 2 == 0) {
+        if ((gy0 & 1) && (gx0 & 1)) {
+            constexpr int BH = PH / 2, BW = PW / 2, UN = 2;
+            const int total = BH * BW * QN;
+            const int i0 = (gy0 - 1) >> 1, j0 = (gx0 - 1) >> 1;
+            const size_t nb = (size_t)n * S.Hs * S.Ws * S.Cs;
+            for (int it0 = tl; it0 < total; it0 += nthr * UN) {
+                f32x4 s[UN][4];
+                int dst[UN], dch[UN], by_[UN], bx_[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int it = min(it0 + u * nthr, total - 1);
+                    const int bb = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - bb * QN;
+                    const int by = bb / BW, bx = bb - by * BW;
+                    const int r0 = min(max(i0 + by, 0), S.Hs - 1), r1 = min(max(i0 + by + 1, 0), S.Hs - 1);
+                    const int c0 = min(max(j0 + bx, 0), S.Ws - 1), c1 = min(max(j0 + bx + 1, 0), S.Ws - 1);
+                    const size_t b = nb + (q_lo + q) * 4;
+                    s[u][0] = ld4x(base, b + ((size_t)r0 * S.Ws + c0) * S.Cs, hf);
+                    s[u][1] = ld4x(base, b + ((size_t)r0 * S.Ws + c1) * S.Cs, hf);
+                    s[u][2] = ld4x(base, b + ((size_t)r1 * S.Ws + c0) * S.Cs, hf);
+                    s[u][3] = ld4x(base, b + ((size_t)r1 * S.Ws + c1) * S.Cs, hf);
+                    dst[u] = (it0 + u * nthr < total) ? (2 * by * PW + 2 * bx) * CSL : -1;
+                    dch[u] = dst_c + q * 4;
+                    by_[u] = by; bx_[u] = bx;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (dst[u] < 0) continue;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int gy = gy0 + 2 * by_[u] + k;
+                        const float sy = fmaxf(gy * 0.5f - 0.25f, 0.f);
+                        const float ly = sy - (float)(int)sy;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int gx = gx0 + 2 * bx_[u] + m;
+                            const float sx = fmaxf(gx * 0.5f - 0.25f, 0.f);
+                            const float lx = sx - (float)(int)sx;
+                            f32x4 o = (1.f - ly) * ((1.f - lx) * s[u][0] + lx * s[u][1]) + ly * ((1.f - lx) * s[u][2] + lx * s[u][3]);
+                            if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) o = f32x4{0, 0, 0, 0};
+                            stp4(patch + dst[u] + (k * PW + m) * CSL, dch[u], o);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    constexpr int UN = UP ? 2 : 4;
+    const int total = PH * PW * QN;
+    for (int it0 = tl; it0 < total; it0 += nthr * UN) {
         f32x4 v[UN];
         int dst[UN], dch[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int it = min(it0 + u * CONV_NT, total - 1);
+            const int it = min(it0 + u * nthr, total - 1);
             const int pp = QN == 1 ? it : (int)__umulhi((unsigned)it, inv), q = it - pp * QN;
             const int py = pp / PW, px = pp - py * PW;
             const int gy = gy0 + py, gx = gx0 + px;
-            const bool inb = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            dst[u] = (it0 + u * CONV_NT < total) ? pp * CSL : -1;
+            dst[u] = (it0 + u * nthr < total) ? pp * CSL : -1;
             dch[u] = dst_c + q * 4;
-            {
-                if (!UP) {
-                    v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + (q_lo + q) * 4, hf);
-                } else {
-                    // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
-                    const float sy = fmaxf(cy * 0.5f - 0.25f, 0.f), sx = fmaxf(cx * 0.5f - 0.25f, 0.f);
-                    const int iy0 = (int)sy, ix0 = (int)sx;
-                    const float ly = sy - iy0, lx = sx - ix0;
-                    const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
-                    const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + (q_lo + q) * 4;
-                    const f32x4 v00 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
-                    const f32x4 v01 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
-                    const f32x4 v10 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
-                    const f32x4 v11 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix1) * S.Cs, hf);
-                    v[u] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-                }
+            if (!UP) {
+                v[u] = ld4x(base, (((size_t)n * H + cy) * W + cx) * S.Cs + (q_lo + q) * 4, hf);
+            } else {
+                // x2 bilinear, align_corners=False (decoder.py:74): src = (dst+0.5)/2-0.5, clamped at 0
+                const float sy = fmaxf(cy * 0.5f - 0.25f, 0.f), sx = fmaxf(cx * 0.5f - 0.25f, 0.f);
+                const int iy0 = (int)sy, ix0 = (int)sx;
+                const float ly = sy - iy0, lx = sx - ix0;
+                const int iy1 = iy0 + (iy0 < S.Hs - 1), ix1 = ix0 + (ix0 < S.Ws - 1);
+                const size_t b = (size_t)n * S.Hs * S.Ws * S.Cs + (q_lo + q) * 4;
+                const f32x4 v00 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix0) * S.Cs, hf);
+                const f32x4 v01 = ld4x(base, b + ((size_t)iy0 * S.Ws + ix1) * S.Cs, hf);
+                const f32x4 v10 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix0) * S.Cs, hf);
+                const f32x4 v11 = ld4x(base, b + ((size_t)iy1 * S.Ws + ix1) * S.Cs, hf);
+                v[u] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
             }
             if (!inb) v[u] = f32x4{0, 0, 0, 0};
         }
@@ -883,6 +936,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     // the two groups' partial accumulators are added through LDS before the epilogue
     const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), kgrp = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: which sources this wave stages (ConvSrc::w0, nw)
     const int nt0 = blockIdx.y * NW;
     bool nv[NW];
 #pragma unroll
@@ -907,8 +961,9 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     }
     auto wload = [&](int gs) {
 #pragma unroll
-        for (int j = 0; j < NPMAX; ++j)
-            if (j < NP) wr[j] = *(const f32x4*)((const char*)a.w + wsrc[j] + (size_t)min(gs + wsx[j], a.KS - 1) * (512 * sizeof(T)));
+        for (int j = 0; j < NPMAX; ++j)      // always NPMAX loads (pieces beyond NP repeat the last one): a count known at
+                                             // compile time lets the compiler wait for exactly these and nothing else
+            wr[j] = *(const f32x4*)((const char*)a.w + wsrc[j] + (size_t)min(gs + wsx[j], a.KS - 1) * (512 * sizeof(T)));
     };
     auto wstore = [&](int buf) {
 #pragma unroll
@@ -935,15 +990,17 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
             for (int s = 0; s < a.nsrc; ++s) {
                 const int C = a.src[s].C;
                 const int lo = max(c_lo, coff), hi = min(c_lo + CCc, coff + C);
-                if (hi > lo && !(a.dbg & 1)) {
+                const bool mine = swave >= a.src[s].w0 && swave < a.src[s].w0 + a.src[s].nw;
+                if (hi > lo && mine && !(a.dbg & 1)) {
                     const int q_lo = (lo - coff) >> 2, q_cnt = (hi - lo) >> 2, dst_c = lo - c_lo;
                     const bool hf = sizeof(T) == 2 || a.src[s].f16;
+                    const int tl = tid - a.src[s].w0 * 64, nthr = a.src[s].nw * 64;
                     if (a.src[s].up) {
-                        if (hf) stage_source<T, true, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
-                        else stage_source<T, true, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tid);
+                        if (hf) stage_source<T, true, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tl, nthr);
+                        else stage_source<T, true, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tl, nthr);
                     } else {
-                        if (hf) stage_source<T, false, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
-                        else stage_source<T, false, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tid);
+                        if (hf) stage_source<T, false, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
+                        else stage_source<T, false, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
                     }
                 }
                 coff += C;
@@ -955,6 +1012,10 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
             }
         }
         if (chunk == 0) wstore(0);
+        // Every load so far has landed (the LDS stores above used them) except, as far as the compiler can tell, the
+        // padding loads of partly filled staging rounds; say so, or it guards the first register reuse in the K loop
+        // with a vmcnt(0) that also waits for the weight stage in flight, on every K step.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
         __syncthreads();
         if (chunk == 0) stamp(1);
 
@@ -1064,8 +1125,30 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     stamp(3);
 }
 
+// Waves of a conv_kxk block per source, in proportion to the loads the source's part of the halo patch takes
+// (the sources lie along a [0, 8) wave axis; a wave on a boundary stages both neighbours, one after the other).
+static void conv_assign_waves(ConvArgs& a, int PH, int PW) {
+    double cost[4], total = 0;
+    for (int k = 0; k < a.nsrc; ++k) {
+        const bool blocks = a.src[k].up && PH % 2 == 0 && PW % 2 == 0;
+        cost[k] = (double)(a.src[k].C / 4) * (blocks ? PH * PW : (a.src[k].up ? 4 : 1) * PH * PW) + 64;
+        total += cost[k];
+    }
+    double at = 0;
+    for (int k = 0; k < a.nsrc; ++k) {
+        const double lo = at / total * 8, hi = (at + cost[k]) / total * 8;
+        int w0 = (int)(lo + 1e-6), w1 = (int)(hi - 1e-6) + 1;
+        if (w0 > 7) w0 = 7;
+        if (w1 > 8) w1 = 8;
+        if (w1 <= w0) w1 = w0 + 1;
+        a.src[k].w0 = w0; a.src[k].nw = w1 - w0;
+        at += cost[k];
+    }
+}
 template <typename T, int MW, int NW, int KD, int S, int D>
-static void launch_conv_t(const ConvArgs& a, int N, hipStream_t s) {
+static void launch_conv_t(const ConvArgs& a_, int N, hipStream_t s) {
+    ConvArgs a = a_;
+    conv_assign_waves(a, ConvGeo<MW, KD, S, D>::PH, ConvGeo<MW, KD, S, D>::PW);
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
@@ -1207,19 +1290,27 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     const int nst = (a.KS - wave + 3) / 4;                           // this wave's K steps: wave, wave + 4, ...
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_step(min(wave + 4 * p, a.KS - 1), p);
-    for (int j0 = 0; j0 < nst; j0 += PF) {
+    auto consume = [&](int p) {
+        Frag<T> xa;
+        if constexpr (QUAD) xa = xq[p].frag(); else xa = xo[p].frag(xh[p]);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) mma(acc[ni], wf[p][ni], xa);
+    };
+    // Groups of PF steps.  Every group but the last refills each slot right after using it, unconditionally (steps
+    // beyond the end repeat the last one and are never used): with a load count that does not depend on run-time
+    // conditions the compiler waits for exactly the slot it needs and leaves the PF - 1 younger ones in flight.
+    // The last group only drains.
+    int j0 = 0;
+    for (; j0 + PF < nst; j0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int j = j0 + p;
-            if (j < nst) {
-                Frag<T> xa;
-                if constexpr (QUAD) xa = xq[p].frag(); else xa = xo[p].frag(xh[p]);
-#pragma unroll
-                for (int ni = 0; ni < NW; ++ni) mma(acc[ni], wf[p][ni], xa);
-                if (j + PF < nst) load_step(wave + 4 * (j + PF), p);
-            }
+            consume(p);
+            load_step(min(wave + 4 * (j0 + p + PF), a.KS - 1), p);
         }
     }
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (j0 + p < nst) consume(p);
     stamp(1);
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) red[wave][ni][lane] = acc[ni];
