@@ -518,6 +518,9 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     }
     __syncthreads();
     stamp(1);
+    // every load requested so far has landed except the first tile's pixels and (conditionally, so the compiler
+    // cannot count them) the fc1 columns: wait for all of them here, once, or every tile of the loop below does
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
     if (KSE > 0 && !(a.dbg & 1)) {
         auto expand_tile = [&](int mt, const XRaw<T>* xf) {
             const int px = mt * 16 + l15;
@@ -536,10 +539,12 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             if (px < NPX) ebuf[g * a.npxs + tile_index(px)] = v;
         };
         // the next tile's pixels are requested before the current tile is multiplied
+        // (requests past the last tile read a dummy address: a load count without conditions lets the compiler
+        //  wait for one tile while the other stays in flight)
         for (int mt = wave; mt < MT; mt += 32) {
-            if (mt + 16 < MT) load_x(mt + 16, xfb);
+            load_x(mt + 16, xfb);
             expand_tile(mt, xfa);
-            if (mt + 32 < MT) load_x(mt + 32, xfa);
+            load_x(mt + 32, xfa);
             if (mt + 16 < MT) expand_tile(mt + 16, xfb);
         }
     } else {

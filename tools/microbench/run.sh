@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/mb -- $R/tools/microbench/floor > $R/gpurun_out/mb_stdout.txt 2>&1
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/mb -- $R/tools/microbench/${MB:-floor} > $R/gpurun_out/mb_stdout.txt 2>&1
 echo exit=$?
 cd $R
 python3 - <<'PY'
@@ -23,4 +23,4 @@ with open('gpurun_out/mb_table.txt', 'w') as o:
         o.write('%-30s blocks %5d x %4d  dur %6.2f us  gap %5.2f us\n' % (k[0], k[1], k[2], a[0]/a[2]/1e3, a[1]/a[2]/1e3))
 PY
 rm -rf gpurun_out/mb
-# build:  for f in floor floor2 cufetch; do hipcc -O3 --offload-arch=gfx950 -o tools/microbench/$f tools/microbench/$f.hip; done
+# build:  for f in floor floor2 cufetch atomics; do hipcc -O3 --offload-arch=gfx950 -o tools/microbench/$f tools/microbench/$f.hip; done
