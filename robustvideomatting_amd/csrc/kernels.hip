@@ -1133,6 +1133,10 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
 // Waves of a conv_kxk block per source, in proportion to the loads the source's part of the halo patch takes
 // (the sources lie along a [0, 8) wave axis; a wave on a boundary stages both neighbours, one after the other).
 static void conv_assign_waves(ConvArgs& a, int PH, int PW) {
+    if (a.nchunks > 1) {                                    // channel chunks cut across the sources: every wave stages every source
+        for (int k = 0; k < a.nsrc; ++k) { a.src[k].w0 = 0; a.src[k].nw = 8; }
+        return;
+    }
     double cost[4], total = 0;
     for (int k = 0; k < a.nsrc; ++k) {
         const bool blocks = a.src[k].up && PH % 2 == 0 && PW % 2 == 0;
