@@ -96,16 +96,13 @@ struct ConvArgs {
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
-// ---- stem ---------------------------------------------------------------------------------
-struct StemArgs {
-    const void* s0; void* y; const float* w /*[27][16]*/; const float* bias /*[16]*/;
-    int Hi, Wi, Ho, Wo; float mean[3]; float std_[3];
-};
-
-// ---- resize / pyramid ----------------------------------------------------------------------
+// ---- resize / pyramid (+ encoder stem) ----------------------------------------------------------------------
 struct DownArgs {
     const void* src; void* s0; void* s1; void* s2; void* s3;
     int H, W, h, w, h1, w1, h2, w2, h3, w3; float scale_y, scale_x;
+    // fused encoder stem (mobilenetv3): normalize + conv3x3 s2 + BN + hardswish of the s0 block just formed; null: none
+    void* stem_y; const float* stem_w /*[27][16]*/; const float* stem_b /*[16]*/;
+    int Ho, Wo; float mean[3]; float std_[3];
 };
 
 struct MaxPoolArgs { const void* x; void* y; int C, Hi, Wi, Ho, Wo; };
@@ -154,7 +151,6 @@ template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s);
 template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s);
-template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s);
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);

@@ -664,14 +664,26 @@ int build_plan(rvm_ctx* c) {
     // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
     T* s[4];
     for (int l = 0; l < 4; ++l) s[l] = abuf((size_t)B * lh[l] * lw[l] * 4);
+    T* stem_out = nullptr;                                   // mobilenetv3: the encoder stem runs inside the downsample launch
     {
-        DownArgs a; a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2]; a.s3 = s[3];
+        DownArgs a; memset(&a, 0, sizeof a);
+        a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2]; a.s3 = s[3];
         a.H = c->H; a.W = c->W; a.h = c->h; a.w = c->w; a.h1 = lh[1]; a.w1 = lw[1]; a.h2 = lh[2]; a.w2 = lw[2]; a.h3 = lh[3]; a.w3 = lw[3];
         a.scale_y = a.scale_x = (c->ds == 1.0) ? 1.f : (float)(1.0 / c->ds);
         // algorithmic bytes: the 2x2 source taps each s0 pixel needs (all of src when ds == 1) + the s0..s3 writes
         const double taps = (c->ds == 1.0) ? 1.0 : 4.0;
         const double pyr = (double)(lh[1] * lw[1] + lh[2] * lw[2] + lh[3] * lw[3]);
-        add("downsample_pyramid", 8.0 * B * c->h * c->w * 3 + 8.0 * B * pyr, (double)B * (c->h * c->w * (3 * taps * ies + 4 * es) + pyr * 4 * es),
+        double sflops = 0, sbytes = 0;
+        if (c->variant == RVM_VARIANT_MOBILENETV3) {
+            stem_out = abuf((size_t)B * lh[1] * lw[1] * 16);
+            a.stem_y = stem_out; a.stem_w = (const float*)(wb + c->stem_w); a.stem_b = (const float*)(wb + c->stem_b);
+            a.Ho = lh[1]; a.Wo = lw[1];
+            const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+            for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
+            sflops = 2.0 * B * a.Ho * a.Wo * 27 * 16; sbytes = (double)B * a.Ho * a.Wo * 16 * es;
+        }
+        add(stem_out ? "downsample_pyramid_stem" : "downsample_pyramid", 8.0 * B * c->h * c->w * 3 + 8.0 * B * pyr + sflops,
+            (double)B * (c->h * c->w * (3 * taps * ies + 4 * es) + pyr * 4 * es) + sbytes,
             [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); });
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
@@ -797,16 +809,8 @@ int build_plan(rvm_ctx* c) {
     int pool_stride = 0;
     if (c->variant == RVM_VARIANT_MOBILENETV3) {
         // ---- encoder (mobilenetv3.py:36-60)
-        T* cur = abuf((size_t)B * lh[1] * lw[1] * 16);
+        T* cur = stem_out;
         int curC = 16, lvl = 1;
-        {
-            StemArgs a; a.s0 = s[0]; a.y = cur; a.w = (const float*)(wb + c->stem_w); a.bias = (const float*)(wb + c->stem_b);
-            a.Hi = lh[0]; a.Wi = lw[0]; a.Ho = lh[1]; a.Wo = lw[1];
-            const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-            for (int k = 0; k < 3; ++k) { a.mean[k] = mean[k]; a.std_[k] = sd[k]; }
-            add("stem_conv3x3s2", 2.0 * B * a.Ho * a.Wo * 27 * 16, (double)B * (a.Hi * a.Wi * 4 + a.Ho * a.Wo * 16) * es,
-                [=](hipStream_t st, const FrameIO&) { launch_stem<T>(a, B, st); });
-        }
         for (int i = 0; i < 15; ++i) {
             const MbBlock& b = c->mb[i];
             const int Hi = lh[lvl], Wi = lw[lvl];

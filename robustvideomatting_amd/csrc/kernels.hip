@@ -1399,53 +1399,6 @@ template void launch_conv3<float>(const ConvArgs&, int, int, int, int, hipStream
 template void launch_conv3<f32s>(const ConvArgs&, int, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-// Stem: ImageNet normalise + 3x3 stride-2 conv 3->16 + BN + hardswish
-// (mobilenetv3.py:37,39; torchvision features[0]).  Normalisation is applied to in-bounds
-// pixels only, so the conv's zero padding pads the *normalised* image like the reference.
-// ------------------------------------------------------------------------------------------
-// Four threads per output pixel, four output channels each: 4x the waves of a thread-per-pixel layout on a
-// grid that is otherwise too small to fill the chip, and a quarter of the FMAs behind each thread's 9 loads.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_conv(StemArgs a) {
-    [[maybe_unused]] Stamper stamp;
-    const int gid = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    const int p = gid >> 2, oq = gid & 3;
-    if (p >= a.Ho * a.Wo) return;
-    const int oy = p / a.Wo, ox = p - oy * a.Wo;
-    float acc[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[o] = a.bias[oq * 4 + o];
-    const T* xb = (const T*)a.s0 + (size_t)n * a.Hi * a.Wi * 4;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy - 1 + ky;
-        if (iy < 0 || iy >= a.Hi) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * ox - 1 + kx;
-            if (ix < 0 || ix >= a.Wi) continue;
-            f32x4 v = ld4f(xb + ((size_t)iy * a.Wi + ix) * 4);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float xn = (v[c] - a.mean[c]) / a.std_[c];
-                const f32x4 w = *(const f32x4*)(a.w + ((ky * 3 + kx) * 3 + c) * 16 + oq * 4);
-#pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] += xn * w[o];
-            }
-        }
-    }
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = act_f(acc[r], ACT_HSWISH);
-    st4f((T*)a.y + ((size_t)n * a.Ho * a.Wo + p) * 16 + oq * 4, v);
-}
-template <typename T> void launch_stem(const StemArgs& a, int N, hipStream_t s) {
-    hipLaunchKernelGGL((stem_conv<T>), dim3((a.Ho * a.Wo * 4 + 255) / 256, N), dim3(256), 0, s, a);
-}
-template void launch_stem<f16>(const StemArgs&, int, hipStream_t);
-template void launch_stem<float>(const StemArgs&, int, hipStream_t);
-
-// ------------------------------------------------------------------------------------------
 // Downsample src (NCHW, full res) -> s0 (NHWC4: r,g,b,gray) with scale-factor-driven
 // bilinear coordinates (model/model.py:80-81: align_corners=False,
 // recompute_scale_factor=False => src = (dst+0.5)/ds - 0.5, clamped at 0).
@@ -1466,7 +1419,7 @@ __device__ __forceinline__ float quad_lane(float v, int k) {        // value of 
     }
     return __builtin_bit_cast(float, r);
 }
-template <typename T, typename TIO>
+template <typename T, typename TIO, bool STEM>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, n = blockIdx.y;
@@ -1478,9 +1431,9 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     const bool inb = oy < a.h && ox < a.w;
     const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * a.H * a.W;
     const size_t plane = (size_t)a.H * a.W;
-    f32x4 o;
-    {
-        const int cy = min(oy, a.h - 1), cx = min(ox, a.w - 1);
+    // one s0 pixel (r, g, b rounded to the storage type; [3] unset)
+    auto interp = [&](int py, int px) {
+        const int cy = min(max(py, 0), a.h - 1), cx = min(max(px, 0), a.w - 1);
         float sy = a.scale_y * (cy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
         float sx = a.scale_x * (cx + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
         int y0 = (int)sy, x0 = (int)sx;
@@ -1488,16 +1441,29 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         if (x0 > a.W - 1) x0 = a.W - 1;
         const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
         const float ly = sy - y0, lx = sx - x0;
+        f32x4 r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const TIO* pl = sp + c * plane;
             const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
             const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
-            o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-            o[c] = (float)(T)o[c];
+            r[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            r[c] = (float)(T)r[c];
         }
-        o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
+        r[3] = 0.f;
+        return r;
+    };
+    f32x4 o = interp(oy, ox);
+    // stem: the conv also needs the s0 row above and the column left of the block (lanes 0..8 / 9..16; the other
+    // lanes repeat their own pixel) - requested together with the block so that it stays one round trip
+    [[maybe_unused]] int hy = oy, hx = ox;
+    [[maybe_unused]] f32x4 hv;
+    if constexpr (STEM) {
+        if (lane < 9) { hy = 8 * y3 - 1; hx = 8 * x3 - 1 + lane; }
+        else if (lane < 17) { hy = 8 * y3 + (lane - 9); hx = 8 * x3 - 1; }
+        hv = interp(hy, hx);
     }
+    o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
     if (inb) st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
     // ---- s1: the quad's valid pixels
     f32x4 v1 = f32x4{0, 0, 0, 0};
@@ -1557,11 +1523,59 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         v3 = v3 / c3;
         st4f((T*)a.s3 + (((size_t)n * a.h3 + y3) * a.w3 + x3) * 4, v3);
     }
+    // ---- encoder stem on the block: ImageNet normalise + 3x3 stride-2 conv 3->16 + BN + hardswish (mobilenetv3.py:37,39;
+    //      torchvision features[0]): 4 x 4 output pixels x 16 channels = 64 lanes x 4 channels.  Normalisation is applied
+    //      to in-bounds pixels only, so the conv's zero padding pads the *normalised* image like the reference; the
+    //      9 x 9 normalised s0 patch goes through the wave's own LDS tile.
+    if constexpr (STEM) {
+        __shared__ f32x4 tiles[4][81];
+        f32x4* tile = tiles[threadIdx.x >> 6];
+        auto norm = [&](f32x4 v, bool ok) {
+            f32x4 r;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = ok ? (v[c] - a.mean[c]) / a.std_[c] : 0.f;
+            r[3] = 0.f;
+            return r;
+        };
+        tile[(dy + 1) * 9 + dx + 1] = norm(o, inb);
+        if (lane < 17) tile[lane < 9 ? lane : (lane - 8) * 9] = norm(hv, hy >= 0 && hx >= 0 && hy < a.h && hx < a.w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int p16 = lane >> 2, oq = lane & 3, py = p16 >> 2, px = p16 & 3;
+        float acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = a.stem_b[oq * 4 + q];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 v = tile[(2 * py + ky) * 9 + 2 * px + kx];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 w = *(const f32x4*)(a.stem_w + ((ky * 3 + kx) * 3 + c) * 16 + oq * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] += v[c] * w[q];
+                }
+            }
+        const int r = 4 * y3 + py, cc = 4 * x3 + px;
+        if (r < a.Ho && cc < a.Wo) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_f(acc[q], ACT_HSWISH);
+            st4f((T*)a.stem_y + (((size_t)n * a.Ho + r) * a.Wo + cc) * 16 + oq * 4, v);
+        }
+    }
 }
 template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
     const dim3 grid((a.h3 * a.w3 + 3) / 4, N);
-    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((downsample<T, T>), grid, dim3(256), 0, s, a);
+    if (a.stem_y) {
+        if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((downsample<T, T, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((downsample<T, T, false>), grid, dim3(256), 0, s, a);
+    }
 }
 template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
 template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
