@@ -117,8 +117,13 @@ struct DgfWeights {                          // device blob layout (floats)
     float seg_w[16];  float seg_b;
 };
 struct DgfLowArgs {
-    const void* hid; const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast;
+    void* hid;                              // [h][w][16]: read (dgf_lowres) or written (dgf_lowres_mfma, which computes it)
+    const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast;
     const void* mlp;                        // deep refiner: 9 MFMA weight fragments (hi/lo fp16), see pack in engine.cpp
+    // dgf_lowres_mfma: the OutputBlock's second conv runs inside it
+    const void* hin;                        // first conv's output [h][w][16]
+    const void* cw; const float* cbias;     // conv3x3 16 -> 16 weight fragments [5][512] and bias (null: dgf_lowres on a given hid)
+    int csplit;                             // fp32 tensors: conv on the split-fp16 MFMA (else fp32 MFMA)
 };
 struct DgfApplyArgs {
     const void* src; const float* ab; void* fgr; void* pha;

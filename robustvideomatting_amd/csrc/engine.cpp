@@ -705,8 +705,10 @@ int build_plan(rvm_ctx* c) {
     };
 
     // KxK conv launcher: (Ho, Wo) output, (Hi, Wi) input of the direct sources
+    // (`keep`: hand the launch back instead of adding it to the frame - the caller schedules it itself)
     auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Ho, int Wo, int Hi, int Wi, int epi,
-                     std::function<void(ConvArgs&, const FrameIO&)> fill, int nb = 0) -> int {
+                     std::function<void(ConvArgs&, const FrameIO&)> fill, int nb = 0,
+                     std::function<void(hipStream_t, const FrameIO&)>* keep = nullptr) -> int {
         const int B = nb ? nb : Bs * TT;                    // samples of this launch (a GRU step: Bs)
         ConvArgs a; memset(&a, 0, sizeof a);
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
@@ -795,9 +797,10 @@ int build_plan(rvm_ctx* c) {
                         conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, a.SK));
         }
         const double KK = (double)L.KD * L.KD;
+        auto fn = [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3_m<T>(b, B, MW, NW, geo, st, split); };
+        if (keep) { *keep = fn; return 0; }
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
-            ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es,
-            [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3_m<T>(b, B, MW, NW, geo, st, split); });
+            ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es, fn);
         return 0;
     };
 
@@ -1038,6 +1041,9 @@ int build_plan(rvm_ctx* c) {
     }
     // decode0 (OutputBlock, decoder.py:127-131)
     const int HC = c->dec[3];
+    const bool conv1_in_dgf = c->ds != 1.0 && c->refiner != RVM_REFINER_FAST_GUIDED_FILTER && !getenv("RVM_DGF_VALU") &&
+                              HC == 16 && c->out1.KS == 5 && c->out1.NT == 1 && c->out1.nchunks == 1;
+    std::function<void(hipStream_t, const FrameIO&)> conv1_fn;
     T* hidA = abuf((size_t)B * c->h * c->w * HC);
     T* hid = abuf((size_t)B * c->h * c->w * HC);
     {
@@ -1051,9 +1057,11 @@ int build_plan(rvm_ctx* c) {
                 a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
+        // The second conv runs inside the deep guided filter's low-res kernel when there is one (ds != 1, MFMA form); a
+        // segmentation pass on such a plan, which skips the filter, still launches it on its own.
         if (conv3("decode0.conv1", c->out1, c->h, c->w, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO&) {
                 a.src[0] = ConvSrc{hidA, HC, HC, 0, 0, 0, 0}; a.nsrc = 1; a.y = hid; a.ys = HC;
-            })) return 1;
+            }, 0, conv1_in_dgf ? &conv1_fn : nullptr)) return 1;
     }
     c->taps["hid"] = Tap{hid, B, c->h, c->w, HC, HC, false};
 
@@ -1062,9 +1070,13 @@ int build_plan(rvm_ctx* c) {
     float* ab = fbuf((size_t)B * c->h * c->w * 8);
     c->taps["ab"] = Tap{ab, B, c->h, c->w, 8, 8, true};
     {
-        DgfLowArgs lo; lo.hid = hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
+        DgfLowArgs lo; memset(&lo, 0, sizeof lo);
+        lo.hid = hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
         lo.fast = c->refiner == RVM_REFINER_FAST_GUIDED_FILTER;
-        lo.mlp = (!lo.fast && !getenv("RVM_DGF_VALU")) ? wb + c->dgf_mlp : nullptr;
+        if (conv1_in_dgf) {
+            lo.mlp = wb + c->dgf_mlp;
+            lo.hin = hidA; lo.cw = wb + c->out1.w; lo.cbias = (const float*)(wb + c->out1.bias); lo.csplit = split ? 1 : 0;
+        }
         DgfApplyArgs ap; ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
         ap.ncols = std::min(c->w, (int)std::ceil(2048.0 * ap.scale_x) + 3);
@@ -1072,8 +1084,15 @@ int build_plan(rvm_ctx* c) {
         const bool refine = c->ds != 1.0;
         const double lowpx = (double)B * c->h * c->w, fullpx = (double)B * c->H * c->W;
         if (refine) {
-            add("dgf_lowres", lowpx * 2.0 * (64 + 4 * 9 * 4 + 24 * 16 + 16 * 16 + 16 * 4), lowpx * (20 * es + 32),
-                [=](hipStream_t st, const FrameIO& io) { if (!io.seg) launch_dgf_low<T>(lo, B, st); });
+            const double dflops = lowpx * 2.0 * (64 + 4 * 9 * 4 + 24 * 16 + 16 * 16 + 16 * 4);
+            if (conv1_in_dgf) {
+                const std::function<void(hipStream_t, const FrameIO&)> conv1 = conv1_fn;
+                add("decode0.conv1_dgf_lowres", dflops + lowpx * 2.0 * 9 * HC * HC, lowpx * (HC * es + HC * es + 4 * es + 32) + 9.0 * HC * HC * es,
+                    [=](hipStream_t st, const FrameIO& io) { if (io.seg) conv1(st, io); else launch_dgf_low<T>(lo, B, st); });
+            } else {
+                add("dgf_lowres", dflops, lowpx * (20 * es + 32),
+                    [=](hipStream_t st, const FrameIO& io) { if (!io.seg) launch_dgf_low<T>(lo, B, st); });
+            }
             add("dgf_apply_fullres", fullpx * 80.0, fullpx * 7 * ies + lowpx * 32,
                 [=](hipStream_t st, const FrameIO& io) {
                     if (io.seg) {

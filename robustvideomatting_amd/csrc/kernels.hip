@@ -1717,46 +1717,112 @@ __device__ __forceinline__ f32x4 mma_hl(f32x4 acc, const f16* wfrag, int lane, c
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, x.hi, acc, 0, 0, 0);
     return acc;
 }
-template <typename T>
+// The OutputBlock's second conv (decoder.py:129-131: conv3x3 16 -> 16 + BN + ReLU) runs inside this kernel: the block
+// computes `hid` on its 18 x 18 halo region out of a 20 x 20 patch of the first conv's output (the same implicit GEMM
+// and weight fragments as conv_kxk: K index = tap * 16 + channel, 5 K steps, one n-tile; 21 m-tiles of 16 pixels over
+// the 4 waves), keeps it in LDS for the projection / the MLP and writes the interior to memory (segmentation pass,
+// debug taps).  One launch and one trip of `hid` through memory less.  TC = arithmetic type of the conv.
+constexpr int DGF_HS = 20;                                              // floats per pixel of the hid tile in LDS (16 + pad)
+template <typename TC> constexpr int dgf_patch_csl() { return 16 + Tr<TC>::kLdsPad; }
+template <typename TC> constexpr size_t dgf_lds_bytes() {
+    size_t patch = (size_t)20 * 20 * dgf_patch_csl<TC>() * sizeof(TC);
+    if (patch < 9 * 1024 * 2) patch = 9 * 1024 * 2;                      // the MLP weight fragments move in once the patch is dead
+    return patch + (size_t)18 * 18 * DGF_HS * 4 + (size_t)2 * 18 * 18 * 16;
+}
+template <typename T, typename TC>
 __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     [[maybe_unused]] Stamper stamp;
-    __shared__ f32x4 sx[18 * 18], sy[18 * 18];
-    __shared__ __attribute__((aligned(16))) f16 wl[9 * 1024];           // W1[t] x4, W2, W3[t] x4
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    constexpr int CSL = dgf_patch_csl<TC>();
+    constexpr size_t PATCHB = dgf_lds_bytes<TC>() - (size_t)18 * 18 * DGF_HS * 4 - (size_t)2 * 18 * 18 * 16;
+    TC* patch = (TC*)dsm;                                               // [20 * 20][CSL], later wl
+    f16* wl = (f16*)dsm;                                                // W1[t] x4, W2, W3[t] x4 (9 x 1024 f16)
+    float* hidt = (float*)(dsm + PATCHB);                               // [18 * 18][DGF_HS]
+    f32x4* sx = (f32x4*)(hidt + 18 * 18 * DGF_HS);
+    f32x4* sy = sx + 18 * 18;
     const DgfWeights& wt = *a.wt;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
     const int y0 = ty * 16, x0 = tx * 16;
-    const T* hid = (const T*)a.hid + (size_t)n * a.h * a.w * 16;
     const T* s0 = (const T*)a.s0 + (size_t)n * a.h * a.w * 4;
-    // Everything this block reads from memory is requested up front, branch-free (clamped addresses, masked
-    // afterwards): MLP weight fragments (18 KiB, 16-byte pieces), the 18 x 18 halo of s0 | hid (two rounds of
-    // 256 threads) and the hid slices this lane supplies to the other three tiles of its wave.
     const int lane = tid & 63, lx = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int gx = x0 + lx;
+    // Everything this block reads from memory is requested up front, branch-free (clamped addresses, masked
+    // afterwards): MLP weight fragments (18 KiB, 16-byte pieces), the conv's weight fragments and bias, the 18 x 18
+    // halo of s0 (two rounds of 256 threads); then the 20 x 20 x 16 patch of the first conv's output is staged.
+    f32x4 wreg[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const int i = min(tid + 256 * j, 1151); wreg[j] = ((const f32x4*)a.mlp)[i]; }
+    Frag<TC> cwf[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) cwf[ks].loadw((const TC*)a.cw + (size_t)ks * 512, lane);
+    const f32x4 cb = *(const f32x4*)(a.cbias + g * 4);
+    f32x4 xr[2]; bool inb[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int pp = min(tid + 256 * r, 323);
+        const int py = pp / 18, px = pp - py * 18;
+        const int gy = y0 + py - 1, gxx = x0 + px - 1;
+        inb[r] = gy >= 0 && gy < a.h && gxx >= 0 && gxx < a.w;
+        xr[r] = ld4f(s0 + (inb[r] ? (size_t)gy * a.w + gxx : 0) * 4);
+    }
+    {
+        const ConvSrc S = ConvSrc{a.hin, 16, 16, 0, 0, 0, 0, 0, 0};
+        stage_source<TC, false, sizeof(T) == 2, 20, 20>(patch, S, 0, 4, 0, CSL, n, y0 - 2, x0 - 2, a.h, a.w, tid, 256);
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- hid = relu(conv3x3(patch) + bias) on the 18 x 18 region
+    // three m-tiles at a time per wave: independent accumulators keep the MFMA pipe busy (one tile alone is a chain of
+    // 15 dependent MFMAs); two such rounds cover the wave's 5-6 tiles.  The results go to the LDS tile at once, to
+    // memory (the block's own 16 x 16 pixels: segmentation pass, debug taps) only after both rounds - a store between
+    // the rounds would have to complete before its registers are reused.
+    T* hout = (T*)a.hid + (size_t)n * a.h * a.w * 16;
+    f32x4 hv_[2][3];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int mt0 = wave + 12 * rd;
+        int pp[3], py[3], px[3];
+        f32x4 acc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            pp[u] = min((mt0 + 4 * u) * 16 + lx, 323);
+            py[u] = pp[u] / 18; px[u] = pp[u] - py[u] * 18;
+            acc[u] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int q8 = ks * 4 + g, tap = min(q8 >> 1, 8), c8 = q8 & 1;      // q8 >= 18: zero weights, any finite operand
+            const int dy = tap / 3, dx = tap - dy * 3;
+            Frag<TC> xf[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) xf[u].load_lds(patch + ((py[u] + dy) * 20 + px[u] + dx) * CSL + c8 * 8);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) mma(acc[u], cwf[ks], xf[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            f32x4 v = acc[u] + cb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)(T)fmaxf(v[r], 0.f);       // as it would come back from memory
+            hv_[rd][u] = v;
+            if ((mt0 + 4 * u) * 16 + lx < 324) *(f32x4*)(hidt + pp[u] * DGF_HS + g * 4) = v;
+        }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int p = (wave + 12 * rd + 4 * u) * 16 + lx;
+            const int py = p / 18, px = p - py * 18;
+            const int gy = y0 + py - 1, gxx = x0 + px - 1;
+            if (p < 324 && py >= 1 && py <= 16 && px >= 1 && px <= 16 && gy < a.h && gxx < a.w)
+                st4f(hout + ((size_t)gy * a.w + gxx) * 16 + g * 4, hv_[rd][u]);
+        }
+    __syncthreads();
+    // ---- guided-filter inputs of the halo: x = [s0 rgb, gray], y = project_mat(hid) (model.py:62); MLP weights into LDS
     f32x4 hs[4][2];
     {
-        f32x4 wreg[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { const int i = min(tid + 256 * j, 1151); wreg[j] = ((const f32x4*)a.mlp)[i]; }
-        f32x4 xr[2]; F8 h0r[2], h1r[2]; bool inb[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int pp = min(tid + 256 * r, 323);
-            const int py = pp / 18, px = pp - py * 18;
-            const int gy = y0 + py - 1, gxx = x0 + px - 1;
-            inb[r] = gy >= 0 && gy < a.h && gxx >= 0 && gxx < a.w;
-            const size_t pix = inb[r] ? (size_t)gy * a.w + gxx : 0;
-            xr[r] = ld4f(s0 + pix * 4);
-            h0r[r] = ld8f(hid + pix * 16); h1r[r] = ld8f(hid + pix * 16 + 8);
-        }
-        F8 hsr[4]; bool hsok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int rg = (g - t) & 3;
-            const int gyt = y0 + 4 * wave + t;
-            hsok[t] = (rg == 1 || rg == 2) && gyt < a.h && gx < a.w;
-            hsr[t] = ld8f(hid + (hsok[t] ? ((size_t)gyt * a.w + gx) * 16 + (rg - 1) * 8 : 0));
-        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int pp = tid + 256 * r;
@@ -1767,7 +1833,10 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
                     xv[3] = (xv[0] + xv[1] + xv[2]) / 3.f;
                     float hv[16];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { hv[k] = h0r[r].lo[k]; hv[4 + k] = h0r[r].hi[k]; hv[8 + k] = h1r[r].lo[k]; hv[12 + k] = h1r[r].hi[k]; }
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 t = *(const f32x4*)(hidt + pp * DGF_HS + 4 * k);
+                        hv[4 * k] = t[0]; hv[4 * k + 1] = t[1]; hv[4 * k + 2] = t[2]; hv[4 * k + 3] = t[3];
+                    }
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         float sacc = wt.proj_b[o];
@@ -1781,14 +1850,20 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) { const int i = tid + 256 * j; if (i < 1152) ((f32x4*)wl)[i] = wreg[j]; }
+        // the hid slices this lane supplies to the other three tiles of its wave
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            hs[t][0] = hsok[t] ? hsr[t].lo : f32x4{0, 0, 0, 0};
-            hs[t][1] = hsok[t] ? hsr[t].hi : f32x4{0, 0, 0, 0};
+            const int rg = (g - t) & 3;
+            const int gyt = y0 + 4 * wave + t;
+            const bool ok = (rg == 1 || rg == 2) && gyt < a.h && gx < a.w;
+            const float* hp = hidt + ((4 * wave + t + 1) * 18 + lx + 1) * DGF_HS + (ok ? (rg - 1) * 8 : 0);
+            const f32x4 h0 = *(const f32x4*)hp, h1 = *(const f32x4*)(hp + 4);
+            hs[t][0] = ok ? h0 : f32x4{0, 0, 0, 0};
+            hs[t][1] = ok ? h1 : f32x4{0, 0, 0, 0};
         }
     }
     __syncthreads();
-    stamp(1);
+    stamp(2);
     // ---- box statistics of this thread's pixel (x = lx, row = 4 * wave + g)
     const int ly = 4 * wave + g;
     f32x4 mx = f32x4{0, 0, 0, 0}, my = mx, exy = mx, exx = mx;
@@ -1808,7 +1883,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         cov[c] = __fsub_rn(exy[c], __fmul_rn(mx[c], my[c]));
         var[c] = __fsub_rn(exx[c], __fmul_rn(mx[c], mx[c]));
     }
-    stamp(2);
+    stamp(3);
     // ---- MLP on the MFMA, tile by tile
     const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g);
     const f32x4 z4 = f32x4{0, 0, 0, 0};
@@ -1834,12 +1909,16 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     float* o = a.ab + (((size_t)n * a.h + gy) * a.w + gx) * 8;
     *(f32x4*)o = A;
     *(f32x4*)(o + 4) = bq;
-    stamp(3);
+    stamp(4);
 }
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s) {
     const int tiles_y = (a.h + 15) / 16;
-    if (!a.fast && a.mlp) hipLaunchKernelGGL((dgf_lowres_mfma<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dgf_lowres<T>), dim3(a.tiles_x * tiles_y, N), dim3(256), 0, s, a);
+    const dim3 grid(a.tiles_x * tiles_y, N);
+    if (a.cw) {                                                           // deep guided filter with the OutputBlock's second conv inside
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((dgf_lowres_mfma<T, f16>), grid, dim3(256), dgf_lds_bytes<f16>(), s, a);
+        else if (a.csplit) hipLaunchKernelGGL((dgf_lowres_mfma<T, f32s>), grid, dim3(256), dgf_lds_bytes<f32s>(), s, a);
+        else hipLaunchKernelGGL((dgf_lowres_mfma<T, float>), grid, dim3(256), dgf_lds_bytes<float>(), s, a);
+    } else hipLaunchKernelGGL((dgf_lowres<T>), grid, dim3(256), 0, s, a);
 }
 template void launch_dgf_low<f16>(const DgfLowArgs&, int, hipStream_t);
 template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
@@ -2224,6 +2303,9 @@ template <typename T> static void conv_attr_all() {
 }
 void kernels_init() {
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
+    (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<f16, f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f16>());
+    (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, f32s>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f32s>());
+    (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<float>());
     (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 #define RVM_ED_ATTR(TT, KK) \
