@@ -60,6 +60,8 @@ struct EdArgs {
     int cw;                                 // channels per block: 16, or 8 (already expanded input only)
     int npxs;                               // pixels per channel-quad plane of the LDS tile (>= rows*Wi of any band, multiple of 16)
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
+    // block 1 (16 -> 16 channels, no expand, no SE): the 1x1 project + BN + residual run in the same launch
+    const float* pj_w; const float* pj_b;   // [16 in][16 out] fp32 (BN folded), [16]; null: none.  y is then the block's output
 };
 
 // ---- small dense layer on pooled vectors (SE fc1/fc2, LR-ASPP gate) ------------------------

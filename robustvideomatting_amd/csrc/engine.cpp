@@ -160,7 +160,10 @@ struct SeLayer { size_t w1f = 0, b1 = 0, w2 = 0, b2 = 0; int C = 0, S = 0; };   
 struct Conv3Layer { size_t w = 0, bias = 0; int Cpad = 0, KS = 0, NT = 0, Cout = 0, Cin = 0; int KD = 3, geo = 0, CC = 0, nchunks = 1; };
 struct ResBlock { PwLayer c1, c3, ds; Conv3Layer c2; bool has_ds = false; int stride = 1, planes = 0, inpl = 0; };
 struct GruLayer { Conv3Layer ih, hh; int C = 0; };
-struct MbBlock { bool has_expand = false, has_se = false, res = false; PwLayer expand, project; DwLayer dw; SeLayer se; MbRow row; };
+struct MbBlock {
+    bool has_expand = false, has_se = false, res = false; PwLayer expand, project; DwLayer dw; SeLayer se; MbRow row;
+    size_t pj_w = 0, pj_b = 0; bool pj = false;     // block 1: project weights as plain fp32 [Cin][Cout] + bias (run inside mbconv_ed)
+};
 
 struct Tap { const void* p; int B, H, W, C, Cs; bool is_float; };
 
@@ -458,6 +461,15 @@ int finalize_impl(rvm_ctx* c) {
             }
             if (!bn_fold(c, p + std::to_string(j) + ".1", r.cout, 1e-3f, af)) return 1;
             if (!pack_pw(c, p + std::to_string(j) + ".0.weight", af, r.exp, r.cout, ACT_NONE, b.project)) return 1;
+            b.pj = !b.has_expand && !b.has_se && b.res && r.exp == 16 && r.cout == 16 && r.k == 3 && r.dil == 1 && r.stride == 1;
+            if (b.pj) {
+                auto W = c->P(p + std::to_string(j) + ".0.weight");
+                std::vector<float> w(256);
+                for (int co = 0; co < 16; ++co)
+                    for (int ci = 0; ci < 16; ++ci) w[(size_t)ci * 16 + co] = (*W)[(size_t)co * 16 + ci] * af.scale[co];
+                b.pj_w = put_floats(c, w);
+                b.pj_b = put_floats(c, af.shift);
+            }
         }
         if (!bn_fold(c, "backbone.features.16.1", 960, 1e-3f, af)) return 1;
         if (!pack_pw(c, "backbone.features.16.0.weight", af, 160, 960, ACT_HSWISH, c->last)) return 1;
@@ -822,7 +834,8 @@ int build_plan(rvm_ctx* c) {
             const int exp = b.row.exp;
             const int K = b.dw.K;
             const int npix = Ho * Wo;
-            T* dwo = abuf((size_t)B * npix * exp);
+            T* dwo = b.pj ? nullptr : abuf((size_t)B * npix * exp);
+            T* pj_done = nullptr;                              // block 1: the fused launch already wrote the block's output
             const T* scale = nullptr;
             // ---- expand -> depthwise (-> SE fc1 partials) in one launch: 16 channels x a band of rows per block
             {
@@ -866,7 +879,10 @@ int build_plan(rvm_ctx* c) {
                 }
                 if (fuse_e) { a.w = wb + b.expand.w; a.KS = b.expand.KS; a.NT = b.expand.NT; a.ebias = (const float*)(wb + b.expand.bias); a.eact = b.expand.act; }
                 a.dw_w = (const float*)(wb + b.dw.w); a.dw_b = (const float*)(wb + b.dw.bias); a.dact = b.dw.act;
-                a.y = dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
+                T* pj_out = b.pj ? abuf((size_t)B * npix * b.row.cout) : nullptr;
+                pj_done = pj_out;
+                if (b.pj) { a.pj_w = (const float*)(wb + b.pj_w); a.pj_b = (const float*)(wb + b.pj_b); }
+                a.y = b.pj ? pj_out : dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
                 a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16);
                 { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
                 if (a.KS > 3 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * Wi >= 65536 || (b.has_se && b.se.S > 1024))
@@ -881,8 +897,8 @@ int build_plan(rvm_ctx* c) {
                     a.fc1_w = (const float*)(wb + b.se.w1f); a.S = b.se.S; a.hpart = hpart;
                 }
                 const double eflops = fuse_e ? 2.0 * B * Hi * Wi * curC * exp : 0.0;
-                add("mb" + std::to_string(i + 1) + (fuse_e || !b.has_expand ? ".expand_dw" : ".dw") + std::to_string(K),
-                    eflops + 2.0 * B * npix * exp * K * K, ((double)B * (Hi * Wi * curC + npix * exp) + (double)curC * exp) * es,
+                add("mb" + std::to_string(i + 1) + (b.pj ? ".dw" : (fuse_e || !b.has_expand ? ".expand_dw" : ".dw")) + std::to_string(K) + (b.pj ? "_project" : ""),
+                    eflops + 2.0 * B * npix * exp * K * K + (b.pj ? 2.0 * B * npix * exp * b.row.cout : 0.0), ((double)B * (Hi * Wi * curC + npix * exp) + (double)curC * exp) * es,
                     [=](hipStream_t st, const FrameIO&) {
                         if constexpr (std::is_same<T, float>::value) { if (split) { launch_ed<f32s>(a, B, K, st); return; } }
                         launch_ed<T>(a, B, K, st);
@@ -900,8 +916,12 @@ int build_plan(rvm_ctx* c) {
                     scale = sc;
                 }
             }
-            T* out = abuf((size_t)B * npix * b.row.cout);
-            pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+            T* out = nullptr;
+            if (b.pj) out = pj_done;
+            else {
+                out = abuf((size_t)B * npix * b.row.cout);
+                pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+            }
             cur = out; curC = b.row.cout; lvl = olvl;
             if (i == 0) f[0] = cur;
             if (i == 2) f[1] = cur;

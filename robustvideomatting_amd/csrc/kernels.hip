@@ -441,7 +441,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (no clamps, no masks in the depthwise loop).
 // KSE = K steps of the fused expand (0: the input is already expanded), compile-time so that the number of loads
 // in flight is known where a tile is consumed (a run-time count makes every wait a wait for ALL loads)
-template <typename T, int K, int KSE>
+template <typename T, int K, int KSE, bool PJ = false>
 __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -513,6 +513,10 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             ebuf[q * a.npxs + (i - q * tcells)] = f32x4{0, 0, 0, 0};
         }
         if (tid < pieces) *(f32x4*)((char*)we + (size_t)tid * 16) = wreg[0];
+        if constexpr (PJ) {                                          // project weights + bias share the (unused) SE scratch
+            if (tid < 256) ((float*)red)[tid] = a.pj_w[tid];
+            else if (tid < 272) ((float*)red)[tid] = a.pj_b[tid - 256];
+        }
         if (tid < K * K * 16) wd[tid] = dwv;
         if (tid >= 1024 - 16) { bd[tid & 15] = bdv; be[tid & 15] = bev; }
     }
@@ -574,6 +578,44 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C;
     const unsigned invWo = 0xFFFFFFFFu / (unsigned)a.Wo + 1u;
     const int rowstep = a.dil * PWt;
+    if constexpr (PJ) {
+        // Block 1 (mobilenetv3.py features[1]: depthwise 3x3 + BN + ReLU -> 1x1 16 -> 16 + BN -> + input): a thread owns
+        // one output pixel with all 16 channels, so the 1x1 runs in registers right behind the depthwise pass (weights
+        // broadcast from LDS) and the residual is the centre tap of the tile.  Stride 1, dilation 1 (host-checked).
+        const float* pjw = (const float*)red;
+        for (int p = tid; p < npo; p += 1024) {
+            const int oyl = (int)__umulhi((unsigned)p, invWo), ox = p - oyl * a.Wo;
+            const f32x4* e0 = ebuf + oyl * PWt + ox;
+            f32x4 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4* eq = e0 + q * a.npxs;
+                f32x4 acc = *(const f32x4*)(bd + q * 4);
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) acc += eq[ky * PWt + kx] * *(const f32x4*)(wd + (ky * K + kx) * 16 + q * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d[q][r] = act_f(acc[r], a.dact);
+                    if constexpr (sizeof(T) == 2) d[q][r] = (float)(f16)d[q][r];          // as the depthwise output would be stored
+                }
+            }
+            T* yp = yb + (size_t)p * 16;
+#pragma unroll
+            for (int qo = 0; qo < 4; ++qo) {
+                asm volatile("" ::: "memory");                       // keep the 272 weight floats in LDS, not hoisted into registers
+                f32x4 o = *(const f32x4*)(pjw + 256 + qo * 4);
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci) o += d[ci >> 2][ci & 3] * *(const f32x4*)(pjw + ci * 16 + qo * 4);
+                o += e0[qo * a.npxs + a.pad * PWt + a.pad];                               // residual: the block's input
+                st4f(yp + qo * 4, o);
+            }
+        }
+        stamp(3);
+        stamp(4);
+        return;
+    }
     for (int it = tid; it < nq * npo_pad; it += 1024) {
         const int q = it / npo_pad, p = it - q * npo_pad;            // q is wave-uniform
         const bool valid = p < npo;
@@ -637,6 +679,7 @@ template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t 
     dim3 grid((a.C + a.cw - 1) / a.cw, a.nband, N);
     const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
     const int kse = a.w ? a.KS : 0;                                  // 0..ED_KSMAX (host-checked)
+    if (a.pj_w) { hipLaunchKernelGGL((mbconv_ed<T, 3, 0, true>), grid, dim3(1024), lds, s, a); return; }      // block 1
 #define RVM_ED_CASE(KK, KS_) if (K == KK && kse == KS_) { hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); return; }
     RVM_ED_CASE(3, 0) RVM_ED_CASE(3, 1) RVM_ED_CASE(3, 2) RVM_ED_CASE(3, 3)
     RVM_ED_CASE(5, 0) RVM_ED_CASE(5, 1) RVM_ED_CASE(5, 2) RVM_ED_CASE(5, 3)
@@ -2315,4 +2358,7 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     RVM_ED_ATTR(f16, 3) RVM_ED_ATTR(f16, 5) RVM_ED_ATTR(float, 3) RVM_ED_ATTR(float, 5) RVM_ED_ATTR(f32s, 3) RVM_ED_ATTR(f32s, 5)
 #undef RVM_ED_ATTR
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
