@@ -852,7 +852,7 @@ template size_t conv_lds_bytes<f32s>(int, int, int, int, int, int, int);
 //                   tiles: origin = even tile corner - 1): item = (2x2 output block, quad); the outputs
 //                   (2i+1, 2i+2) x (2j+1, 2j+2) interpolate between the SAME source pixels (i, i+1) x (j, j+1),
 //                   4 loads for 4 outputs.  Weights, clamps and zero padding as in the per-pixel form.
-template <typename T, bool UP, bool HF, int PH, int PW>
+template <typename T, bool UP, bool HF, int PH, int PW, int UND = 4>
 __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo, int q_cnt, int dst_c, int CSL, int n,
                                              int gy0, int gx0, int H, int W, int tl, int nthr) {
     const int QN = q_cnt;
@@ -916,7 +916,7 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
             return;
         }
     }
-    constexpr int UN = UP ? 2 : 4;
+    constexpr int UN = UP ? 2 : UND;                         // loads in flight per thread (UND: direct sources)
     const int total = PH * PW * QN;
     for (int it0 = tl; it0 < total; it0 += nthr * UN) {
         f32x4 v[UN];
@@ -1770,14 +1770,14 @@ template <typename TC> constexpr int dgf_patch_csl() { return 16 + Tr<TC>::kLdsP
 template <typename TC> constexpr size_t dgf_lds_bytes() {
     size_t patch = (size_t)20 * 20 * dgf_patch_csl<TC>() * sizeof(TC);
     if (patch < 9 * 1024 * 2) patch = 9 * 1024 * 2;                      // the MLP weight fragments move in once the patch is dead
-    return patch + (size_t)18 * 18 * DGF_HS * 4 + (size_t)2 * 18 * 18 * 16;
+    return patch + (size_t)18 * 18 * DGF_HS * 4 + (size_t)2 * 18 * 18 * 16 + 68 * 4 + 16;
 }
 template <typename T, typename TC>
 __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int CSL = dgf_patch_csl<TC>();
-    constexpr size_t PATCHB = dgf_lds_bytes<TC>() - (size_t)18 * 18 * DGF_HS * 4 - (size_t)2 * 18 * 18 * 16;
+    constexpr size_t PATCHB = dgf_lds_bytes<TC>() - (size_t)18 * 18 * DGF_HS * 4 - (size_t)2 * 18 * 18 * 16 - 68 * 4 - 16;
     TC* patch = (TC*)dsm;                                               // [20 * 20][CSL], later wl
     f16* wl = (f16*)dsm;                                                // W1[t] x4, W2, W3[t] x4 (9 x 1024 f16)
     float* hidt = (float*)(dsm + PATCHB);                               // [18 * 18][DGF_HS]
@@ -1809,10 +1809,14 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         inb[r] = gy >= 0 && gy < a.h && gxx >= 0 && gxx < a.w;
         xr[r] = ld4f(s0 + (inb[r] ? (size_t)gy * a.w + gxx : 0) * 4);
     }
+    float* pjl = (float*)(sy + 18 * 18);                                // project_mat weights [4][16] + bias [4], via LDS
+    const float pjv = ((const float*)&wt.proj_w[0][0])[min(tid, 67)];   // proj_w and proj_b are adjacent in DgfWeights
     {
         const ConvSrc S = ConvSrc{a.hin, 16, 16, 0, 0, 0, 0, 0, 0};
-        stage_source<TC, false, sizeof(T) == 2, 20, 20>(patch, S, 0, 4, 0, CSL, n, y0 - 2, x0 - 2, a.h, a.w, tid, 256);
+        // 1600 items over 256 threads: 7 per thread, all in flight at once
+        stage_source<TC, false, sizeof(T) == 2, 20, 20, 7>(patch, S, 0, 4, 0, CSL, n, y0 - 2, x0 - 2, a.h, a.w, tid, 256);
     }
+    if (tid < 68) pjl[tid] = pjv;
     __syncthreads();
     stamp(1);
     // ---- hid = relu(conv3x3(patch) + bias) on the 18 x 18 region
@@ -1852,6 +1856,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
             if ((mt0 + 4 * u) * 16 + lx < 324) *(f32x4*)(hidt + pp[u] * DGF_HS + g * 4) = v;
         }
     }
+    stamp(2);
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
@@ -1862,7 +1867,9 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
             if (p < 324 && py >= 1 && py <= 16 && px >= 1 && px <= 16 && gy < a.h && gxx < a.w)
                 st4f(hout + ((size_t)gy * a.w + gxx) * 16 + g * 4, hv_[rd][u]);
         }
+    stamp(3);
     __syncthreads();
+    stamp(4);
     // ---- guided-filter inputs of the halo: x = [s0 rgb, gray], y = project_mat(hid) (model.py:62); MLP weights into LDS
     f32x4 hs[4][2];
     {
@@ -1882,9 +1889,9 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
                     }
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
-                        float sacc = wt.proj_b[o];
+                        float sacc = pjl[64 + o];
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) sacc += wt.proj_w[o][k] * hv[k];
+                        for (int k = 0; k < 16; ++k) sacc += pjl[o * 16 + k] * hv[k];
                         yv[o] = sacc;
                     }
                 }
@@ -1906,7 +1913,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         }
     }
     __syncthreads();
-    stamp(2);
+    stamp(5);
     // ---- box statistics of this thread's pixel (x = lx, row = 4 * wave + g)
     const int ly = 4 * wave + g;
     f32x4 mx = f32x4{0, 0, 0, 0}, my = mx, exy = mx, exx = mx;
@@ -1926,7 +1933,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         cov[c] = __fsub_rn(exy[c], __fmul_rn(mx[c], my[c]));
         var[c] = __fsub_rn(exx[c], __fmul_rn(mx[c], mx[c]));
     }
-    stamp(3);
+    stamp(6);
     // ---- MLP on the MFMA, tile by tile
     const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g);
     const f32x4 z4 = f32x4{0, 0, 0, 0};
@@ -1952,7 +1959,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     float* o = a.ab + (((size_t)n * a.h + gy) * a.w + gx) * 8;
     *(f32x4*)o = A;
     *(f32x4*)(o + 4) = bq;
-    stamp(4);
+    stamp(7);
 }
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s) {
     const int tiles_y = (a.h + 15) / 16;
