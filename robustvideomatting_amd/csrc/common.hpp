@@ -44,6 +44,10 @@ struct PwArgs {
     int HW; int MT; int NT; int act;
     int act_post;                           // apply `act` after the residual add (resnet bottleneck)
     int sstride, sHi, sWi, sWo;             // sstride > 1: strided 1x1 (input HxW = sHi x sWi, output width sWo)
+    // Small squeeze-excite layers (S <= 32, Cin <= 256, <= 256 partial rows): the SE tail runs in this kernel's prologue
+    // instead of a gemv launch: scale = hardsigmoid(fc2(relu(xscale * sum of fc1 partials + b1)) + b2); in_scale == null
+    const float* se_hpart; int se_nparts, se_S; float se_xscale;    // partial fc1 pre-activations [N][nparts][S]
+    const float* se_b1; const void* se_w2 /* T [Cin][S] */; const float* se_b2;
 };
 
 // ---- fused expand (1x1, MFMA) -> depthwise k x k (LDS) [-> squeeze-excite fc1 partial] -----------

@@ -701,15 +701,22 @@ int build_plan(rvm_ctx* c) {
     }
 
     bool plan_bad = false;
-    struct PwX { int act_post = 0, sstride = 1, sHi = 0, sWi = 0, sWo = 0; };
+    struct PwX {
+        int act_post = 0, sstride = 1, sHi = 0, sWi = 0, sWo = 0;
+        // squeeze-excite tail inside the GEMM's prologue (see PwArgs)
+        const float* se_hpart = nullptr; int se_nparts = 0, se_S = 0; float se_xscale = 0.f;
+        const float* se_b1 = nullptr; const void* se_w2 = nullptr; const float* se_b2 = nullptr;
+    };
     auto pw = [&](const std::string& name, const PwLayer& L, const T* x, int xs, int HW, T* y, int ys, const T* in_scale, const T* res, int rs,
                   const float* out_scale, float* pool, PwX ex = PwX()) {
         PwArgs a; memset(&a, 0, sizeof a);
         a.act_post = ex.act_post; a.sstride = ex.sstride; a.sHi = ex.sHi; a.sWi = ex.sWi; a.sWo = ex.sWo;
+        a.se_hpart = ex.se_hpart; a.se_nparts = ex.se_nparts; a.se_S = ex.se_S; a.se_xscale = ex.se_xscale; a.se_b1 = ex.se_b1; a.se_w2 = ex.se_w2; a.se_b2 = ex.se_b2;
         a.x = x; a.Cin = L.Cin; a.xs = xs; a.w = wb + L.w; a.KS = L.KS; a.bias = (const float*)(wb + L.bias);
         a.in_scale = in_scale; a.res = res; a.rs = rs; a.out_scale = out_scale; a.oss = L.Cout;
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
         if (in_scale && (L.KS * 32 > 1024 || L.Cin % 4)) { fail("pw_gemm: input scale vector too long"); plan_bad = true; return; }
+        if (ex.se_hpart && (in_scale || L.Cin > 256 || ex.se_S > 32 || ex.se_S % 4 || ex.se_nparts > 256)) { fail("pw_gemm: squeeze-excite tail too large for the prologue"); plan_bad = true; return; }
         const int cfg = tune_pick(name, 7, pick_pw_cfg(a.MT, a.NT, a.KS, B));
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
@@ -836,6 +843,7 @@ int build_plan(rvm_ctx* c) {
             const int npix = Ho * Wo;
             T* dwo = b.pj ? nullptr : abuf((size_t)B * npix * exp);
             T* pj_done = nullptr;                              // block 1: the fused launch already wrote the block's output
+            PwX se_x;                                          // squeeze-excite tail handed to the project GEMM (small SE layers)
             const T* scale = nullptr;
             // ---- expand -> depthwise (-> SE fc1 partials) in one launch: 16 channels x a band of rows per block
             {
@@ -903,7 +911,12 @@ int build_plan(rvm_ctx* c) {
                         if constexpr (std::is_same<T, float>::value) { if (split) { launch_ed<f32s>(a, B, K, st); return; } }
                         launch_ed<T>(a, B, K, st);
                     });
-                if (b.has_se) {
+                // Small SE layers (the 1/8-scale blocks: S = 24 / 32, <= 120 channels): the tail below fits the prologue
+                // of the project GEMM, one launch less each
+                if (b.has_se && b.se.S <= 32 && b.se.S % 4 == 0 && exp <= 256 && nparts <= 256 && !getenv("RVM_SE_GEMV")) {
+                    se_x.se_hpart = hpart; se_x.se_nparts = nparts; se_x.se_S = b.se.S; se_x.se_xscale = 1.f / (float)npix;
+                    se_x.se_b1 = (const float*)(wb + b.se.b1); se_x.se_w2 = wb + b.se.w2; se_x.se_b2 = (const float*)(wb + b.se.b2);
+                } else if (b.has_se) {
                     // scale = hardsigmoid(fc2(relu(fc1(mean)))): the fc1 pre-activations arrive as per-block partials
                     T* sc = abuf((size_t)B * exp);
                     GemvArgs g2; memset(&g2, 0, sizeof g2);
@@ -920,7 +933,7 @@ int build_plan(rvm_ctx* c) {
             if (b.pj) out = pj_done;
             else {
                 out = abuf((size_t)B * npix * b.row.cout);
-                pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr);
+                pw("mb" + std::to_string(i + 1) + ".project", b.project, dwo, exp, npix, out, b.row.cout, scale, b.res ? cur : nullptr, curC, nullptr, nullptr, se_x);
             }
             cur = out; curC = b.row.cout; lvl = olvl;
             if (i == 0) f[0] = cur;

@@ -12,6 +12,7 @@
 // Reference arithmetic each kernel replaces is cited at the kernel (paths under
 // /root/reference).
 #include "common.hpp"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Optional in-kernel timeline (build with -DRVM_STAMPS -> librvm_mi355x_stamps.so, tools/stamp_table.py):
@@ -227,12 +228,60 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     // requested first, parked in LDS behind the operand prefetch and applied where a fragment is used
     extern __shared__ __attribute__((aligned(16))) char pw_smem[];
     T* scl = (T*)pw_smem;
-    const bool has_sc = a.in_scale != nullptr;
+    const bool se_tail = a.se_hpart != nullptr;
+    const bool has_sc = a.in_scale != nullptr || se_tail;
     const int sci = threadIdx.x * 4;
     f32x4 scv = f32x4{0, 0, 0, 0};
-    if (has_sc && sci < a.Cin) scv = ld4f((const T*)a.in_scale + (size_t)n * a.Cin + sci);   // Cin % 4 == 0 for SE widths
+    if (a.in_scale && sci < a.Cin) scv = ld4f((const T*)a.in_scale + (size_t)n * a.Cin + sci);   // Cin % 4 == 0 for SE widths
+    // SE tail in the prologue (small layers): thread t holds partial rows pg, pg + 8, ... of fc1 output t % 32 and row t of
+    // fc2; everything is requested here, in front of the operand prefetch, and reduced in stage_scale()
+    constexpr int SEP = 32;                                  // partial rows per thread at most (8 groups x 32 = 256 rows)
+    typedef typename std::conditional<sizeof(T) == 2, f16, float>::type TS;   // storage type of fc2 / the scale vector
+    float se_h[SEP];
+    f32x4 se_w[8];
+    float se_b1v = 0.f, se_b2v = 0.f;
+    if (se_tail) {
+        const int sidx = threadIdx.x & 31, pg = threadIdx.x >> 5;
+        const float* hp = a.se_hpart + (size_t)n * a.se_nparts * a.se_S + min(sidx, a.se_S - 1);
+#pragma unroll
+        for (int j = 0; j < SEP; ++j) se_h[j] = hp[(size_t)min(pg + 8 * j, a.se_nparts - 1) * a.se_S];
+        const TS* wr = (const TS*)a.se_w2 + (size_t)min((int)threadIdx.x, a.Cin - 1) * a.se_S;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) se_w[k] = ld4f(wr + min(4 * k, a.se_S - 4));       // S % 4 == 0 (host-checked)
+        se_b1v = a.se_b1[min((int)threadIdx.x, a.se_S - 1)];
+        se_b2v = a.se_b2[min((int)threadIdx.x, a.Cin - 1)];
+    }
     auto stage_scale = [&]() {
-        if (has_sc) {
+        if (se_tail) {
+            float* part = (float*)(pw_smem + (size_t)a.KS * 32 * sizeof(T));      // [8][32]
+            float* hs = part + 256;                                                // [32]
+            const int t = threadIdx.x, sidx = t & 31, pg = t >> 5;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < SEP; ++j) s += (pg + 8 * j < a.se_nparts) ? se_h[j] : 0.f;
+            part[pg * 32 + sidx] = s;
+            __syncthreads();
+            if (t < 32) {
+                float h = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h += part[q * 32 + t];
+                hs[t] = t < a.se_S ? fmaxf(h * a.se_xscale + se_b1v, 0.f) : 0.f;
+            }
+            __syncthreads();
+            if (t < a.KS * 32) {
+                float acc = se_b2v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (4 * k < a.se_S) {
+                        const f32x4 hv = *(const f32x4*)(hs + 4 * k);
+                        acc += (se_w[k][0] * hv[0] + se_w[k][1] * hv[1]) + (se_w[k][2] * hv[2] + se_w[k][3] * hv[3]);
+                    }
+                }
+                const float v = t < a.Cin ? act_f(acc, ACT_HSIGMOID) : 0.f;      // zeros beyond Cin
+                ((TS*)scl)[t] = (TS)v;
+            }
+            __syncthreads();
+        } else if (has_sc) {
             if (sci < a.KS * 32) st4f(scl + sci, scv);       // zeros beyond Cin
             __syncthreads();
         }
@@ -388,7 +437,7 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
-    const size_t lds = a.in_scale ? (size_t)a.KS * 32 * sizeof(T) : 0;       // the SE scale vector
+    const size_t lds = (a.in_scale || a.se_hpart) ? (size_t)a.KS * 32 * sizeof(T) + (a.se_hpart ? (256 + 32) * 4 : 0) : 0;   // the SE scale vector (+ SE tail scratch)
     switch (cfg) {
         case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2, 1>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), lds, s, a); break;
         case 1: hipLaunchKernelGGL((pw_gemm<T, 1, 1, 2, 2, 1>), dim3(cdiv(a.MT, 2), cdiv(a.NT, 2), N), dim3(256), lds, s, a); break;
