@@ -100,6 +100,19 @@ def test_fp16_hd_frame(gc):
     assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
 
 
+def test_full_size_lowres_batch2_all_modes(gc):
+    """The HD frame's 270x480 low-res map with two streams, in every arithmetic mode: the launches that carry a
+    neighbour's work (stem in the downsample kernel, block 1's project, SE tails in the project GEMMs, the OutputBlock
+    conv in the guided filter) on full-size grids with a batch index."""
+    w = gc.run("fp32", H=540, W=960, ds=0.5, T=2, B=2, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=540, W=960, ds=0.5, T=2, B=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    w = gc.run("fp16fast", H=540, W=960, ds=0.5, T=2, B=2, verbose=False)
+    assert w["fgr"] < 2e-2 and w["pha"] < 2e-2, w          # fp16 arithmetic: fp16 accuracy, not the parity-gated mode
+
+
 def test_fp16_4k_frame(gc):
     """BASELINE configs[2]: 3840x2160, ds=0.125."""
     w = gc.run("fp16", H=2160, W=3840, ds=0.125, T=1, verbose=False)
