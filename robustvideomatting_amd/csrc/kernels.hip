@@ -1316,10 +1316,11 @@ template <> __device__ __forceinline__ Frag<f16> SkQuads<f16>::frag() const {
     const f16x4 a = __builtin_convertvector(value(0), f16x4), b = __builtin_convertvector(value(1), f16x4);
     Frag<f16> f; f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); return f;
 }
-template <typename T, int NW, bool QUAD>
-__global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
+// WS = waves per block = ways the K steps are split (4, or 8 for long K on grids that leave CUs idle)
+template <typename T, int NW, bool QUAD, int WS>
+__global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
     [[maybe_unused]] Stamper stamp;
-    __shared__ f32x4 red[4][NW][64];
+    __shared__ f32x4 red[WS][NW][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int tx = blockIdx.x % a.tiles_x, y = blockIdx.x / a.tiles_x, n = blockIdx.z;
     const int H = a.H, W = a.W;
@@ -1388,9 +1389,9 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     f32x4 acc[NW];
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) acc[ni] = f32x4{0, 0, 0, 0};
-    const int nst = (a.KS - wave + 3) / 4;                           // this wave's K steps: wave, wave + 4, ...
+    const int nst = (a.KS - wave + WS - 1) / WS;                     // this wave's K steps: wave, wave + WS, ...
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load_step(min(wave + 4 * p, a.KS - 1), p);
+    for (int p = 0; p < PF; ++p) load_step(min(wave + WS * p, a.KS - 1), p);
     auto consume = [&](int p) {
         Frag<T> xa;
         if constexpr (QUAD) xa = xq[p].frag(); else xa = xo[p].frag(xh[p]);
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             consume(p);
-            load_step(min(wave + 4 * (j0 + p + PF), a.KS - 1), p);
+            load_step(min(wave + WS * (j0 + p + PF), a.KS - 1), p);
         }
     }
 #pragma unroll
@@ -1418,7 +1419,10 @@ __global__ __launch_bounds__(256) void conv_sk(ConvArgs a) {
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int ni = 0; ni < NW; ++ni) acc[ni] = (red[0][ni][lane] + red[1][ni][lane]) + (red[2][ni][lane] + red[3][ni][lane]);
+    for (int ni = 0; ni < NW; ++ni) {
+        acc[ni] = (red[0][ni][lane] + red[1][ni][lane]) + (red[2][ni][lane] + red[3][ni][lane]);
+        if constexpr (WS == 8) acc[ni] += (red[4][ni][lane] + red[5][ni][lane]) + (red[6][ni][lane] + red[7][ni][lane]);
+    }
 
     // ---- epilogue (wave 0): lane holds channels g*4..g*4+3 of pixel px for every n-tile; same arithmetic as conv_kxk
     if (px >= W) return;
@@ -1472,8 +1476,17 @@ template <typename T, int NW> static void launch_conv_sk(const ConvArgs& a, int 
     dim3 grid(a.tiles_x * a.H, (a.NT + NW - 1) / NW, N);
     bool quad = false;                                               // a source whose channel count is not a multiple of 8
     for (int k = 0; k < a.nsrc; ++k) quad |= (a.src[k].C % 8) != 0;
-    if (quad) hipLaunchKernelGGL((conv_sk<T, NW, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_sk<T, NW, false>), grid, dim3(256), 0, s, a);
+    // 8 waves per block (each takes every 8th K step) when the grid is small and K is long enough to give every wave a
+    // few steps: twice the loads in flight per CU (measured: 17x30 ConvGRU 8.0 / 8.3 -> 7.0 / 6.5 us)
+    const long nblk = (long)grid.x * grid.y * grid.z;
+    const bool ws8 = a.KS >= 20 && (nblk <= 160 || (NW == 1 && nblk <= 512));   // (two n-tiles: the 512-thread blocks of a larger grid no longer fit at once)
+    if (ws8) {
+        if (quad) hipLaunchKernelGGL((conv_sk<T, NW, true, 8>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_sk<T, NW, false, 8>), grid, dim3(512), 0, s, a);
+    } else {
+        if (quad) hipLaunchKernelGGL((conv_sk<T, NW, true, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_sk<T, NW, false, 4>), grid, dim3(256), 0, s, a);
+    }
 }
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
     if (MW == 0) { if (NW == 2) launch_conv_sk<T, 2>(a, N, s); else launch_conv_sk<T, 1>(a, N, s); return; }   // small-map form
