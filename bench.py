@@ -33,7 +33,7 @@ WORKLOADS = {
 }
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
 MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense peak of the MFMA the mode issues (f16 / f16 split / f32)
-PMC_FILES = {"hd": "profiles/r01/pmc_hd_v7.json", "4k": "profiles/r01/pmc_4k_v7.json"}   # tools/run_pmc.sh output of this command
+PMC_FILES = {"hd": "profiles/r01/pmc_hd_v8.json", "4k": "profiles/r01/pmc_4k_v8.json"}   # tools/run_pmc.sh output of this command
 
 
 def frame_algorithmic_bytes(H, W, h, w, es):
