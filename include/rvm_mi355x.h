@@ -97,6 +97,19 @@ int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_
                 const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
                 void* workspace, double* sums, void* hip_stream);
 
+/* rvm_metrics without any allocation and without a workspace argument.  NO COUNTERPART IN THE REFERENCE: it exists
+ * for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  Same kernels and bit-identical sums as rvm_metrics; the per-tile partial sums live in a
+ * file-scope device array of rvm_metrics_static_capacity() bytes (4 MiB, held by every GPU the library runs on
+ * until the process ends).  Requests with rvm_metrics_workspace(N, H, W) above that capacity are rejected with an
+ * error (e.g. more than 21 frames of 3840x2160 per call).  Runs on the calling thread's CURRENT device, which must
+ * own all the buffers.  Calls that overlap on one GPU (two streams / threads) share the array and race: serialise
+ * them or use rvm_metrics.  Calls no hipMalloc / hipFree / allocating library routine. */
+int64_t rvm_metrics_static_capacity(void);
+int rvm_metrics_static(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                       const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                       double* sums, void* hip_stream);
+
 /* Debug / test taps: copy an intermediate activation of the LAST forward to host as fp32 NCHW.
  * Names: s0 s1 s2 s3 f1 f2 f3 f4 aspp x3 x2 x1 hid ab.  Synchronises the device. */
 int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capacity, int64_t shape[4]);

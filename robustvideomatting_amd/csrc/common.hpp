@@ -156,6 +156,8 @@ struct MetricArgs {
     float g[9], dg[9];                              // separable 9x9 Gaussian-derivative filter: K[i][j] = g[i] * dg[j]
 };
 void launch_metrics(const MetricArgs& a, int N, hipStream_t s);
+constexpr size_t METRIC_SCRATCH_BYTES = 4u << 20;      // static device scratch of rvm_metrics_static (per GPU)
+int metrics_scratch(float** out);                       // its address on the CURRENT device (0 ok, 1 bad device, 2 symbol lookup failed)
 
 // launchers (kernels.hip)
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s);

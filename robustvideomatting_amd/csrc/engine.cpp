@@ -3,7 +3,7 @@
 //
 // The schedule mirrors MattingNetwork.forward (reference model/model.py:40-71):
 //   downsample -> encoder -> LR-ASPP -> recurrent decoder -> projection -> refiner -> clamp
-// but as ~75 fused launches on NHWC buffers instead of ~110 ATen ops on NCHW.
+// but as 56 fused launches per frame (mobilenetv3) on NHWC buffers instead of ~110 ATen ops on NCHW.
 #include "common.hpp"
 #include "../../include/rvm_mi355x.h"
 
@@ -22,6 +22,20 @@ namespace {
 thread_local std::string g_err;
 int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// Every ABI entry point that touches the device runs with the context's device current and puts the caller's
+// device back on exit (a forward on a cuda:1 tensor must not change the calling thread's current device).
+struct DeviceGuard {
+    int prev = -1; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVGUARD(dev) DeviceGuard guard_(dev); if (guard_.err != hipSuccess) return fail(std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
@@ -206,6 +220,7 @@ struct rvm_ctx {
     struct Launch {
         std::string name; double flops, bytes;     // algorithmic work of the launch
         std::function<void(hipStream_t, const FrameIO&)> fn;
+        int edge;                                  // 1 / 2: first / last launches, the only ones that touch src / fgr / pha
     };
     std::vector<Launch> launches;
     std::map<std::string, Tap> taps;
@@ -236,6 +251,8 @@ struct rvm_ctx {
         return arena + off;     // arena == nullptr during the sizing pass
     }
     void drop_graphs() {
+        if (graphs.empty()) return;
+        (void)hipDeviceSynchronize();              // an exec may still be in flight on the caller's stream
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
     }
@@ -584,7 +601,6 @@ int finalize_impl(rvm_ctx* c) {
                 }
         }
     }
-    HIPCHK(hipSetDevice(c->device));
     if (c->wdev) { HIPCHK(hipFree(c->wdev)); c->wdev = nullptr; }
     HIPCHK(hipMalloc((void**)&c->wdev, c->blob.size()));
     HIPCHK(hipMemcpy(c->wdev, c->blob.data(), c->blob.size(), hipMemcpyHostToDevice));
@@ -669,8 +685,8 @@ int build_plan(rvm_ctx* c) {
     const int* lh = c->lh; const int* lw = c->lw;
     auto abuf = [&](size_t elems) { return (T*)c->arena_alloc(elems * es); };
     auto fbuf = [&](size_t elems) { return (float*)c->arena_alloc(elems * 4); };
-    auto add = [&](const std::string& name, double flops, double bytes, std::function<void(hipStream_t, const FrameIO&)> f) {
-        c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f)});
+    auto add = [&](const std::string& name, double flops, double bytes, std::function<void(hipStream_t, const FrameIO&)> f, int edge = 0) {
+        c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f), edge});
     };
 
     // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
@@ -696,7 +712,7 @@ int build_plan(rvm_ctx* c) {
         }
         add(stem_out ? "downsample_pyramid_stem" : "downsample_pyramid", 8.0 * B * c->h * c->w * 3 + 8.0 * B * pyr + sflops,
             (double)B * (c->h * c->w * (3 * taps * ies + 4 * es) + pyr * 4 * es) + sbytes,
-            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); });
+            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); }, 1);
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
@@ -818,8 +834,22 @@ int build_plan(rvm_ctx* c) {
         const double KK = (double)L.KD * L.KD;
         auto fn = [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3_m<T>(b, B, MW, NW, geo, st, split); };
         if (keep) { *keep = fn; return 0; }
-        add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout,
-            ((double)B * (Hi * Wi * L.Cin + Ho * Wo * L.Cout) + KK * L.Cin * L.Cout) * es, fn);
+        // algorithmic bytes: every source at the resolution and element size it is READ at (a x2-upsampled source is
+        // read at half size, an fp16 state as 2 bytes), the epilogue's own operands, the output(s), the weights once
+        double px_bytes = 0;
+        {
+            ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
+            fill(probe, none);
+            for (int k = 0; k < probe.nsrc; ++k) {
+                const ConvSrc& S = probe.src[k];
+                px_bytes += (double)(S.up ? S.Hs * S.Ws : Hi * Wi) * S.C * (S.f16 ? 2 : es);
+            }
+            const double opx = (double)Ho * Wo, ses_ = probe.state16 ? 2 : es;
+            if (epi == EPI_RELU) px_bytes += opx * L.Cout * es;
+            else if (epi == EPI_GRU_IH) px_bytes += opx * probe.hC * (es + 4);                    // r*h and z out (h is a source)
+            else px_bytes += opx * probe.hC * (4 + ses_ + ses_);                                   // z and h in, h' out
+        }
+        add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout, (double)B * px_bytes + KK * L.Cin * L.Cout * es, fn);
         return 0;
     };
 
@@ -1135,13 +1165,13 @@ int build_plan(rvm_ctx* c) {
                         DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
                         launch_dgf_apply<T>(q, B, io16, st);
                     }
-                });
+                }, 2);
         } else {
             add("project_out", lowpx * 2.0 * 64, lowpx * (16 * es + 7 * ies),
                 [=](hipStream_t st, const FrameIO& io) {
                     ProjOutArgs q = po; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha; q.seg = (int)io.seg;
                     launch_proj_out<T>(q, B, io16, st);
-                });
+                }, 2);
         }
     }
     return plan_bad ? 1 : 0;
@@ -1175,6 +1205,7 @@ int autotune(rvm_ctx* c) {
     }
     TUNECHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     TUNECHK(hipEventCreate(&e0)); TUNECHK(hipEventCreate(&e1));
+    TUNECHK(hipDeviceSynchronize());                         // the null-stream memsets (arena, dummy states) before the non-blocking stream runs
     const auto tunable = c->tunable;                      // build_plan refills the list
     const bool verbose = getenv("RVM_VERBOSE") != nullptr;
     for (const auto& t : tunable) {
@@ -1231,7 +1262,6 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (c->h < 1 || c->w < 1) return fail("rvm_plan: downsampled frame is empty");
     c->lh[0] = c->h; c->lw[0] = c->w;
     for (int l = 1; l < 5; ++l) { c->lh[l] = (c->lh[l - 1] + 1) / 2; c->lw[l] = (c->lw[l - 1] + 1) / 2; }
-    HIPCHK(hipSetDevice(c->device));
     c->drop_graphs();
     if (c->arena) { HIPCHK(hipFree(c->arena)); c->arena = nullptr; }
     c->planned = false;
@@ -1242,6 +1272,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     c->arena_bytes = c->arena_used + 256;
     HIPCHK(hipMalloc((void**)&c->arena, c->arena_bytes));
     HIPCHK(hipMemset(c->arena, 0, c->arena_bytes));
+    HIPCHK(hipDeviceSynchronize());                           // the caller's (possibly non-blocking) stream must see the zeros
     rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
     if (rc) return rc;
     {
@@ -1272,7 +1303,7 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("rvm_create: no such HIP device");
-    HIPCHK(hipSetDevice(device));
+    DEVGUARD(device);
     static bool inited[64] = {false};
     if (device < 64 && !inited[device]) { kernels_init(); inited[device] = true; }
     rvm_ctx* c = new rvm_ctx();
@@ -1288,7 +1319,8 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
 
 void rvm_destroy(rvm_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard_(c->device);
+    (void)hipDeviceSynchronize();          // graphs / arena may still be in flight on the caller's streams
     c->drop_graphs();
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     if (c->wdev) (void)hipFree(c->wdev);
@@ -1324,16 +1356,19 @@ int rvm_set_param(rvm_ctx* c, const char* name, const float* data, int64_t numel
 
 int rvm_finalize(rvm_ctx* c) {
     if (!c) return fail("rvm_finalize: null ctx");
+    DEVGUARD(c->device);
     return finalize_impl(c);
 }
 
 int rvm_plan(rvm_ctx* c, int B, int H, int W, double ds) {
     if (!c) return fail("rvm_plan: null ctx");
+    DEVGUARD(c->device);
     return plan_impl(c, B, 1, H, W, ds);
 }
 
 int rvm_plan_seq(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (!c) return fail("rvm_plan_seq: null ctx");
+    DEVGUARD(c->device);
     return plan_impl(c, B, T, H, W, ds);
 }
 
@@ -1349,6 +1384,7 @@ int rvm_launch_count(const rvm_ctx* c) { return c ? (int)c->launches.size() : 0;
 
 int rvm_set_graph_mode(rvm_ctx* c, int enabled) {
     if (!c) return fail("rvm_set_graph_mode: null ctx");
+    DEVGUARD(c->device);
     c->graph_mode = enabled != 0;
     if (!c->graph_mode) c->drop_graphs();
     return 0;
@@ -1367,24 +1403,42 @@ int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fg
         if (io.r_out[i] == io.r_in[i]) return fail("rvm_forward: r_out must not alias r_in");
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    DEVGUARD(c->device);                                     // launches, capture stream and graphs belong to the context's device
     if (!c->graph_mode) {
         for (auto& f : c->launches) f.fn(st, io);
         HIPCHK(hipGetLastError());
         return 0;
     }
-    for (auto& g : c->graphs)
-        if (g.key == io) { HIPCHK(hipGraphLaunch(g.exec, st)); return 0; }
-    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-    hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-    for (auto& f : c->launches) f.fn(c->cap_stream, io);
-    HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
+    // Graph mode: the launches that touch src / fgr / pha (the first and the last of the schedule) run eagerly around a
+    // HIP graph of everything in between, so a replay only needs the STATE pointers to repeat (the caller's ring of
+    // state buffers) - a driver may hand in a new src tensor and take fresh fgr / pha tensors every call.
+    const size_t nl = c->launches.size();
+    size_t lo = 0, hi = nl;
+    while (lo < nl && c->launches[lo].edge == 1) ++lo;
+    while (hi > lo && c->launches[hi - 1].edge == 2) --hi;
+    for (size_t i = 0; i < lo; ++i) c->launches[i].fn(st, io);
+    FrameIO key = io; key.src = nullptr; key.fgr = nullptr; key.pha = nullptr;
     hipGraphExec_t exec = nullptr;
-    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
-    c->graphs.push_back({io, exec});
+    for (auto& g : c->graphs)
+        if (g.key == key) { exec = g.exec; break; }
+    if (!exec) {
+        if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        for (size_t i = lo; i < hi; ++i) c->launches[i].fn(c->cap_stream, io);
+        HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (c->graphs.size() >= 8) {
+            HIPCHK(hipStreamSynchronize(st));                  // the evicted exec may still be running there
+            (void)hipGraphExecDestroy(c->graphs.front().exec);
+            c->graphs.erase(c->graphs.begin());
+        }
+        c->graphs.push_back({key, exec});
+    }
     HIPCHK(hipGraphLaunch(exec, st));
+    for (size_t i = hi; i < nl; ++i) c->launches[i].fn(st, io);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1404,6 +1458,7 @@ int rvm_profile_frame(rvm_ctx* c, const void* src, const void* const r_in[4], vo
     if (!c || !c->planned) return fail("rvm_profile_frame: no plan");
     const int n = (int)c->launches.size();
     if (!ms_out || cap < n) return fail("rvm_profile_frame: ms_out too small");
+    DEVGUARD(c->device);
     FrameIO io; memset(&io, 0, sizeof io);
     io.src = src; io.fgr = fgr; io.pha = pha; io.seg = 0;
     for (int i = 0; i < 4; ++i) { io.r_in[i] = r_in ? r_in[i] : nullptr; io.r_out[i] = r_out[i]; }
@@ -1438,9 +1493,9 @@ int64_t rvm_metrics_workspace(int N, int H, int W) {
     return (int64_t)N * cdiv(W, METRIC_TILE) * cdiv(H, METRIC_TILE) * METRIC_NSUM * (int64_t)sizeof(float);
 }
 
-int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
-                const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
-                void* workspace, double* sums, void* hip_stream) {
+static int metrics_impl(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                        const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                        void* workspace, double* sums, void* hip_stream) {
     if (!pred_pha || !true_pha || !workspace || !sums) return fail("rvm_metrics: null buffer");
     if (N < 1 || N > 65535 || H < 1 || W < 1) return fail("rvm_metrics: bad shape");
     if ((pred_prev == nullptr) != (true_prev == nullptr)) return fail("rvm_metrics: previous frames come in pairs");
@@ -1468,6 +1523,29 @@ int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_
     return 0;
 }
 
+int rvm_metrics(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                void* workspace, double* sums, void* hip_stream) {
+    return metrics_impl(pred_pha, true_pha, pred_prev, true_prev, pred_fgr, true_fgr, N, H, W, sigma, workspace, sums, hip_stream);
+}
+
+// Allocation-free variant: same kernels, the per-tile partial sums go to the library's static device array
+// (kernels.hip `scratch`) instead of a caller workspace.  No hipMalloc / hipFree / allocating routine on this path.
+int64_t rvm_metrics_static_capacity(void) { return (int64_t)METRIC_SCRATCH_BYTES; }
+int rvm_metrics_static(const float* pred_pha, const float* true_pha, const float* pred_prev, const float* true_prev,
+                       const float* pred_fgr, const float* true_fgr, int N, int H, int W, double sigma,
+                       double* sums, void* hip_stream) {
+    const int64_t need = rvm_metrics_workspace(N, H, W);
+    if (need < 0) return fail("rvm_metrics_static: bad shape");
+    if (need > (int64_t)METRIC_SCRATCH_BYTES)
+        return fail("rvm_metrics_static: N x tiles needs " + std::to_string(need) + " bytes of scratch, the static array holds " +
+                    std::to_string(METRIC_SCRATCH_BYTES) + " (use rvm_metrics with a workspace, or fewer frames per call)");
+    float* ws = nullptr;
+    const int rc = metrics_scratch(&ws);
+    if (rc) return fail(rc == 1 ? "rvm_metrics_static: no usable current HIP device" : "rvm_metrics_static: hipGetSymbolAddress(scratch) failed");
+    return metrics_impl(pred_pha, true_pha, pred_prev, true_prev, pred_fgr, true_fgr, N, H, W, sigma, ws, sums, hip_stream);
+}
+
 int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
     if (!out || capacity < 2 * 512 * 16 || !nlaunch) return fail("rvm_debug_stamps: need room for 2*512*16 values");
     unsigned int n[2] = {0, 0};
@@ -1485,7 +1563,7 @@ int rvm_debug_tap(rvm_ctx* c, const char* name, float* out, int64_t cap, int64_t
     const int64_t n = (int64_t)t.B * t.C * t.H * t.W;
     if (!out) return 0;
     if (cap < n) return fail("rvm_debug_tap: output too small");
-    HIPCHK(hipSetDevice(c->device));
+    DEVGUARD(c->device);
     HIPCHK(hipDeviceSynchronize());
     const size_t es = t.is_float ? 4 : c->esize();
     const size_t pixels = (size_t)t.B * t.H * t.W;

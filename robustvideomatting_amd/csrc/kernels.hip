@@ -12,6 +12,7 @@
 // Reference arithmetic each kernel replaces is cited at the kernel (paths under
 // /root/reference).
 #include "common.hpp"
+#include <mutex>
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------
@@ -2366,6 +2367,28 @@ __global__ __launch_bounds__(64) void matte_metrics_sum(MetricArgs a, int nblk) 
 void launch_metrics(const MetricArgs& a, int N, hipStream_t s) {
     hipLaunchKernelGGL(matte_metrics, dim3(a.tiles_x, a.tiles_y, N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(matte_metrics_sum, dim3(N), dim3(64), 0, s, a, a.tiles_x * a.tiles_y);
+}
+
+// Scratch of the allocation-free entry point rvm_metrics_static (include/rvm_mi355x.h): the per-tile partial sums of
+// matte_metrics live in this file-scope device array instead of a caller-provided workspace.  Every GPU the library
+// runs on holds its own copy (METRIC_SCRATCH_BYTES, until the process ends) at its own address; the array's NAME is
+// only a host-side handle, so the device address is looked up once per device with hipGetSymbolAddress (with that
+// device current) and every kernel argument uses that pointer.  Nothing in it has to start at zero: matte_metrics
+// writes every slot matte_metrics_sum reads.  Calls that overlap on one GPU share the array and race.
+static __device__ __align__(256) float scratch[METRIC_SCRATCH_BYTES / sizeof(float)];
+static float* g_scratch_ptr[64];                       // per HIP device ordinal
+static std::mutex g_scratch_mu;
+int metrics_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return 2;
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -93,8 +93,11 @@ class MattingNetwork(nn.Module):
         self.fp16_arithmetic = "fp32"   # half() module: "fp32" = fp16 tensors, fp32 math inside (meets 2e-3);
         #                                 "fp16" = fp16 storage + fp16 MFMA inside (fastest, fp16 accuracy)
         self.chunk_batching = True  # [B,T,...] input: one native call per chunk (rvm_plan_seq) instead of T calls
-        self._ring = {}             # plan key -> ring of static output/state buffers (graph mode)
+        self._ring = {}             # plan key -> ring of static state buffers (graph mode)
         self._ring_pos = 0
+        self._live = None           # live floating-point parameter / buffer tensors, for the in-place edit check
+        self._live_sig = None       # (sum of their _version counters, sum of data_ptr) at the last upload
+        self._calls = 0
 
     # ---- bookkeeping: any .to()/.half()/.cuda()/load_state_dict invalidates the packed weights.
     # fp32 MASTER copies of the parameters are kept across .half(): the native packer folds
@@ -124,10 +127,32 @@ class MattingNetwork(nn.Module):
         self._master = None
         self._dirty = True
 
+    def _signature(self):
+        if self._live is None:
+            self._live = [v for v in self.state_dict().values() if v.is_floating_point()]
+        return (sum(v._version for v in self._live), sum(v.data_ptr() for v in self._live))
+
+    def _check_in_place_edits(self):
+        """In-place edits of the live parameters (an optimiser step, ``p.mul_()``, ``p.data = ...``) make the fp32
+        masters stale: compare the tensors' version counters / storage with what was uploaded and, on a change, drop
+        the masters and re-pack.  Checked on every call while autograd is enabled and on every 64th call under
+        ``torch.no_grad()`` (the inference loop); writes through ``p.data.copy_()`` bump no counter - call
+        ``refresh()`` after those."""
+        self._calls += 1
+        if self._dirty or self._live_sig is None:
+            return
+        if not torch.is_grad_enabled() and (self._calls & 63):
+            return
+        if self._signature() != self._live_sig:
+            self._master = None
+            self._dirty = True
+
     def enable_graph(self, on: bool = True):
-        """Replay the per-frame schedule as a HIP graph.  Outputs and states then live in a
-        ring of two static buffer sets per shape: a returned tensor is overwritten by the
-        second-next call (inference.py consumes them immediately, reference inference.py:129-141)."""
+        """Replay the per-frame schedule as a HIP graph (default: off, eager launches - equally fast for one
+        stream).  The recurrent states then live in a ring of two static buffer sets per shape:
+        a returned r1..r4 tensor is overwritten by the second-next call (inference.py hands them straight back,
+        reference inference.py:129).  src may be a new tensor every call and fgr / pha are fresh tensors: the
+        launches that touch them run outside the graph."""
         self._graph = bool(on)
         if self._ctx is not None:
             self._ctx.set_graph_mode(self._graph)
@@ -166,6 +191,8 @@ class MattingNetwork(nn.Module):
             self._ctx.finalize()
             self._dirty = False
             self._ring = {}
+            self._live = None
+            self._live_sig = self._signature()
         return self._ctx
 
     # ---- the hot path
@@ -202,6 +229,7 @@ class MattingNetwork(nn.Module):
         wdtype = self.project_mat.conv.weight.dtype
         if src.dtype != wdtype:
             raise RuntimeError("Input type (%s) and weight type (%s) should be the same" % (src.dtype, wdtype))
+        self._check_in_place_edits()
         ctx = self._native(src.device, src.dtype)
         five = src.ndim == 5
         if five:
@@ -241,30 +269,22 @@ class MattingNetwork(nn.Module):
         out0 = torch.empty((T,) + oshape0, device=dev, dtype=dt)
         out1 = None if seg else torch.empty((T,) + oshape1, device=dev, dtype=dt)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ring = self._static_ring(ctx, shapes, (B, 3, H, W), (B, 1, H, W), dev, dt) if self._graph else None
+        ring = self._static_ring(ctx, shapes, dev, dt) if self._graph else None
         for t in range(T):
             f = frames[t]
             if not f.is_contiguous():
                 f = f.contiguous()
-            if ring is not None and not seg:
-                # static buffers => stable pointers => the captured HIP graph can be replayed
-                slot = ring[self._ring_pos]
-                self._ring_pos = (self._ring_pos + 1) % len(ring)
-                new, o0, o1 = slot["r"], slot["fgr"], slot["pha"]
+            if ring is not None:
+                # static state buffers => stable pointers => the captured HIP graph can be replayed
+                new = self._ring_next(ring, rec)
             else:
                 new = [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
-                o0, o1 = out0[t], (None if seg else out1[t])
+            o0, o1 = out0[t], (None if seg else out1[t])
             rin = [r.data_ptr() if r is not None else 0 for r in rec]
             if seg:
                 ctx.forward(f.data_ptr(), rin, 0, o0.data_ptr(), [n.data_ptr() for n in new], True, stream)
             else:
                 ctx.forward(f.data_ptr(), rin, o0.data_ptr(), o1.data_ptr(), [n.data_ptr() for n in new], False, stream)
-                if ring is not None:
-                    if T == 1:
-                        out0, out1 = o0.unsqueeze(0), o1.unsqueeze(0)
-                    else:
-                        out0[t].copy_(o0)
-                        out1[t].copy_(o1)
             rec = new
         if five:
             outs = [out0.transpose(0, 1)] if seg else [out0.transpose(0, 1), out1.transpose(0, 1)]
@@ -281,15 +301,13 @@ class MattingNetwork(nn.Module):
             tb = tb.contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
         rin = [r.data_ptr() if r is not None else 0 for r in rec]
-        if self._graph and not seg:
-            ring = self._static_ring(ctx, shapes, (T * B, 3, H, W), (T * B, 1, H, W), dev, dt)
-            slot = ring[self._ring_pos]
-            self._ring_pos = (self._ring_pos + 1) % len(ring)
-            new, o0, o1 = slot["r"], slot["fgr"], slot["pha"]
+        if self._graph:
+            ring = self._static_ring(ctx, shapes, dev, dt)
+            new = self._ring_next(ring, rec)
         else:
             new = [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
-            o0 = torch.empty((T * B, 1, h0, w0) if seg else (T * B, 3, H, W), device=dev, dtype=dt)
-            o1 = None if seg else torch.empty((T * B, 1, H, W), device=dev, dtype=dt)
+        o0 = torch.empty((T * B, 1, h0, w0) if seg else (T * B, 3, H, W), device=dev, dtype=dt)
+        o1 = None if seg else torch.empty((T * B, 1, H, W), device=dev, dtype=dt)
         if seg:
             ctx.forward(tb.data_ptr(), rin, 0, o0.data_ptr(), [n.data_ptr() for n in new], True, stream)
             outs = [o0.view(T, B, 1, h0, w0).transpose(0, 1)]
@@ -298,17 +316,25 @@ class MattingNetwork(nn.Module):
             outs = [o0.view(T, B, 3, H, W).transpose(0, 1), o1.view(T, B, 1, H, W).transpose(0, 1)]
         return [*outs, *new]
 
-    def _static_ring(self, ctx, shapes, fshape, pshape, dev, dt):
+    def _static_ring(self, ctx, shapes, dev, dt):
         key = (ctx.plan_key, dev, dt)
         ring = self._ring.get(key)
         if ring is None:
-            ring = [dict(r=[torch.zeros(s, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
-                            for s in shapes],
-                         fgr=torch.empty(fshape, device=dev, dtype=dt),
-                         pha=torch.empty(pshape, device=dev, dtype=dt)) for _ in range(2)]
+            ring = [[torch.zeros(s, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last) for s in shapes]
+                    for _ in range(2)]
             self._ring = {key: ring}
             self._ring_pos = 0
         return ring
+
+    def _ring_next(self, ring, rec):
+        """Next state buffer set of the ring that is not the one the incoming states live in."""
+        ins = {r.data_ptr() for r in rec if r is not None}
+        for _ in range(len(ring)):
+            new = ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % len(ring)
+            if not any(n.data_ptr() in ins for n in new):
+                return new
+        raise RuntimeError("graph mode: the incoming states occupy every buffer set of the ring")
 
     def debug_tap(self, name):
         """fp32 NCHW copy of an intermediate activation of the last frame (tests only)."""

@@ -19,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward",
-    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -75,6 +75,10 @@ def lib():
     L.rvm_metrics_workspace.restype = ctypes.c_int64
     L.rvm_metrics.argtypes = [fp, fp, fp, fp, fp, fp, ci, ci, ci, ctypes.c_double, vp, vp, vp]
     L.rvm_metrics.restype = ci
+    L.rvm_metrics_static_capacity.argtypes = []
+    L.rvm_metrics_static_capacity.restype = ctypes.c_int64
+    L.rvm_metrics_static.argtypes = [fp, fp, fp, fp, fp, fp, ci, ci, ci, ctypes.c_double, vp, vp]
+    L.rvm_metrics_static.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
     L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
@@ -114,6 +118,13 @@ def metrics(pred, true, pred_prev, true_prev, pred_fgr, true_fgr, N, H, W, sigma
     P = lambda p: ctypes.c_void_p(p) if p else None
     check(lib().rvm_metrics(P(pred), P(true), P(pred_prev), P(true_prev), P(pred_fgr), P(true_fgr), N, H, W, float(sigma),
                             P(workspace), P(sums), P(stream)), "rvm_metrics")
+
+
+def metrics_static(pred, true, pred_prev, true_prev, pred_fgr, true_fgr, N, H, W, sigma, sums, stream):
+    """rvm_metrics_static: no workspace, no allocation (static device scratch); runs on the current device."""
+    P = lambda p: ctypes.c_void_p(p) if p else None
+    check(lib().rvm_metrics_static(P(pred), P(true), P(pred_prev), P(true_prev), P(pred_fgr), P(true_fgr), N, H, W,
+                                   float(sigma), P(sums), P(stream)), "rvm_metrics_static")
 
 
 def debug_stamps():

@@ -84,33 +84,37 @@ def make_params(variant="mobilenetv3", refiner="deep_guided_filter", seed=0,
     return out
 
 
+def clip_frames(T, H, W, seed=0, B=1, noise=0.04, _gen=None):
+    """Generator over the frames [3,H,W] of stream 0 of make_clip(T, H, W, seed) (same values, same RNG order)
+    without holding the clip: a 300-frame HD clip is 7.5 GB as one fp32 tensor."""
+    g = _gen if _gen is not None else torch.Generator().manual_seed(1000 + seed)
+    ys = torch.linspace(0, 1, H).view(H, 1)
+    xs = torch.linspace(0, 1, W).view(1, W)
+    b = 0 if _gen is None else B
+    # low-frequency background: a few random sinusoids per channel
+    bg = torch.zeros(3, H, W)
+    for c in range(3):
+        acc = torch.zeros(H, W)
+        for _ in range(4):
+            fy, fx = (torch.rand(2, generator=g) * 3.0 + 0.3).tolist()
+            ph = (torch.rand(1, generator=g) * 6.28).item()
+            amp = (torch.rand(1, generator=g) * 0.15 + 0.05).item()
+            acc = acc + amp * torch.sin(6.28 * (fy * ys + fx * xs) + ph)
+        bg[c] = 0.5 + acc
+    col = torch.rand(3, generator=g) * 0.6 + 0.2
+    cx0, cy0 = (torch.rand(2, generator=g) * 0.4 + 0.3).tolist()
+    for t in range(T):
+        cx = cx0 + 0.15 * math.sin(0.07 * t + b)
+        cy = cy0 + 0.10 * math.cos(0.05 * t + 2 * b)
+        d2 = ((xs - cx) / 0.18) ** 2 + ((ys - cy) / 0.30) ** 2
+        m = torch.sigmoid((1.0 - d2) * 6.0)
+        fr = bg * (1 - m) + col.view(3, 1, 1) * m
+        fr = fr + (torch.rand(3, H, W, generator=g) - 0.5) * noise
+        yield fr.clamp(0, 1)
+
+
 def make_clip(T, H, W, seed=0, B=1, dtype=torch.float32, noise=0.04):
     """[B,T,3,H,W] clip in [0,1]: smooth static background + moving soft ellipse + noise."""
     g = torch.Generator().manual_seed(1000 + seed)
-    clips = []
-    ys = torch.linspace(0, 1, H).view(H, 1)
-    xs = torch.linspace(0, 1, W).view(1, W)
-    for b in range(B):
-        # low-frequency background: a few random sinusoids per channel
-        bg = torch.zeros(3, H, W)
-        for c in range(3):
-            acc = torch.zeros(H, W)
-            for _ in range(4):
-                fy, fx = (torch.rand(2, generator=g) * 3.0 + 0.3).tolist()
-                ph = (torch.rand(1, generator=g) * 6.28).item()
-                amp = (torch.rand(1, generator=g) * 0.15 + 0.05).item()
-                acc = acc + amp * torch.sin(6.28 * (fy * ys + fx * xs) + ph)
-            bg[c] = 0.5 + acc
-        col = torch.rand(3, generator=g) * 0.6 + 0.2
-        cx0, cy0 = (torch.rand(2, generator=g) * 0.4 + 0.3).tolist()
-        frames = []
-        for t in range(T):
-            cx = cx0 + 0.15 * math.sin(0.07 * t + b)
-            cy = cy0 + 0.10 * math.cos(0.05 * t + 2 * b)
-            d2 = ((xs - cx) / 0.18) ** 2 + ((ys - cy) / 0.30) ** 2
-            m = torch.sigmoid((1.0 - d2) * 6.0)
-            fr = bg * (1 - m) + col.view(3, 1, 1) * m
-            fr = fr + (torch.rand(3, H, W, generator=g) - 0.5) * noise
-            frames.append(fr.clamp(0, 1))
-        clips.append(torch.stack(frames))
+    clips = [torch.stack(list(clip_frames(T, H, W, seed, b, noise, _gen=g))) for b in range(B)]
     return torch.stack(clips).to(dtype)

@@ -335,29 +335,57 @@ def test_foreign_nchw_state_is_accepted():
 
 
 # ------------------------------------------------------------------ drift
-@pytest.mark.parametrize("dtype,tol", [("fp32", TOL32), ("fp16", TOL16)])
-def test_no_drift_over_300_frames(gc, dtype, tol):
-    """T=300 with carried state: the error must stay inside the bound at every frame and must not
-    grow (last third no worse than 2x the first third)."""
+def _drift(dtype, tol, T, H, W, ds, state_tol, variant="mobilenetv3"):
+    """T frames with carried state against the oracle, frame by frame (the clip is generated on the fly): the error
+    stays inside the bound at every frame and does not grow (last third no worse than 2x the first third)."""
     from oracle import rvm_oracle as O
     from robustvideomatting_amd import synthetic
     tdt = torch.float32 if dtype == "fp32" else torch.float16
-    m, p = _setup(tdt)
-    T, H, W, ds = 300, 96, 160, 0.5
-    clip = synthetic.make_clip(T, H, W, seed=9)
-    dev_clip = clip.cuda().to(tdt)
-    ref_clip = dev_clip.float().cpu()
+    m, p = _setup(tdt, variant=variant)
     rg, ro = [None] * 4, [None] * 4
     errs = []
     with torch.no_grad():
-        for t in range(T):
-            og = m(dev_clip[:, t], None, *rg, ds)
-            oo = O.forward(p, ref_clip[:, t], *ro, downsample_ratio=ds)
+        for fr in synthetic.clip_frames(T, H, W, seed=9):
+            dev = fr[None].cuda().to(tdt)
+            og = m(dev, None, *rg, ds)
+            oo = O.forward(p, dev.float().cpu(), *ro, downsample_ratio=ds, variant=variant)
             rg, ro = og[2:], oo[2:]
-            errs.append(max((og[0].float().cpu() - oo[0]).abs().max().item(),
-                            (og[1].float().cpu() - oo[1]).abs().max().item()))
+            errs.append(max((og[0].float() - oo[0].cuda()).abs().max().item(),
+                            (og[1].float() - oo[1].cuda()).abs().max().item()))
     errs = np.array(errs)
     assert errs.max() < tol, errs.max()
-    assert errs[200:].mean() <= 2.0 * errs[:100].mean() + 1e-7, (errs[:100].mean(), errs[200:].mean())
+    third = max(T // 3, 1)
+    assert errs[-third:].mean() <= 2.0 * errs[:third].mean() + 1e-7, (errs[:third].mean(), errs[-third:].mean())
     state_err = max((a.float().cpu() - b).abs().max().item() for a, b in zip(rg, ro))
-    assert state_err < (1e-4 if dtype == "fp32" else 1e-2), state_err
+    assert state_err < state_tol, state_err
+    return errs
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", TOL32), ("fp16", TOL16)])
+def test_no_drift_over_300_frames(dtype, tol):
+    """T=300 with carried state at a small size; the recurrent state itself stays inside the output bound."""
+    _drift(dtype, tol, T=300, H=96, W=160, ds=0.5, state_tol=tol)
+
+
+def test_config1_hd_fp16_T300_drift():
+    """BASELINE configs[1] at its real size and length: 1920x1080, ds=0.25, fp16, T=300 with carried state."""
+    _drift("fp16", TOL16, T=300, H=1080, W=1920, ds=0.25, state_tol=TOL16)
+
+
+def test_config2_4k_fp16_carried_state():
+    """BASELINE configs[2] at its real size: 3840x2160, ds=0.125, fp16; frames 2 and 3 consume the recurrent state."""
+    _drift("fp16", TOL16, T=3, H=2160, W=3840, ds=0.125, state_tol=TOL16)
+
+
+def test_config0_512x288_ds1_fp32_T30():
+    """BASELINE configs[0] at its real size: 512x288, ds=1 (no refiner), fp32, T=30."""
+    _drift("fp32", TOL32, T=30, H=288, W=512, ds=1.0, state_tol=TOL32)
+
+
+def test_config4_hd_fp16_batch8_autotuned_plan(gc):
+    """The per-GPU share of BASELINE configs[4]: 8 HD streams batched, fp16, two frames (the second consumes the state),
+    with the tiles the plan-time measurement really picks for B=8."""
+    w = gc.run("fp16", H=1080, W=1920, ds=0.25, T=2, B=8, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    for k in ("r1", "r2", "r3", "r4"):
+        assert w[k] < TOL16, w
