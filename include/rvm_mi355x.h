@@ -26,8 +26,15 @@ typedef struct rvm_ctx rvm_ctx;
 /* RVM_DTYPE_F32   : fp32 tensors, fp32 arithmetic (v_mfma_f32_16x16x4_f32)
  * RVM_DTYPE_F16   : fp16 tensors, fp16 storage and v_mfma_f32_16x16x32_f16 inside (fastest, fp16 accuracy)
  * RVM_DTYPE_F16IO : fp16 tensors at the boundary (src, fgr, pha, r1..r4), fp32 storage and arithmetic
- *                   inside - the mode that meets the 2e-3 fp16 parity bound on any weights */
-enum { RVM_DTYPE_F32 = 0, RVM_DTYPE_F16 = 1, RVM_DTYPE_F16IO = 2 };
+ *                   inside - the mode that meets the 2e-3 fp16 parity bound on any weights
+ * RVM_DTYPE_BF16IO: bf16 tensors at the boundary, the same fp32-accurate interior as F16IO (decoder.py:184-185: states and
+ *                   outputs follow src.dtype for any dtype)
+ * In the two 16-bit I/O modes a context also keeps the fp32 value of every recurrent state it hands out and uses it, element
+ * by element, wherever the state that comes back rounds to exactly that value (i.e. the caller returned our state, the normal
+ * recurrence, inference.py:129) - the state is then never re-rounded to 16 bits from frame to frame (no drift against the fp32
+ * reference over long clips); a foreign or edited state is taken at its 16-bit value.  One context = one stream (or one batch
+ * of streams): interleaving unrelated streams through one context is correct but falls back to 16-bit state precision. */
+enum { RVM_DTYPE_F32 = 0, RVM_DTYPE_F16 = 1, RVM_DTYPE_F16IO = 2, RVM_DTYPE_BF16IO = 3 };
 enum { RVM_VARIANT_MOBILENETV3 = 0, RVM_VARIANT_RESNET50 = 1 };
 enum { RVM_REFINER_DEEP_GUIDED_FILTER = 0, RVM_REFINER_FAST_GUIDED_FILTER = 1 };
 
@@ -74,7 +81,7 @@ int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* 
  * (inference.py:116,137-141: com = fgr*pha + bgr*(1-pha) with bgr = (120,255,155)/255 for video output;
  * cat[fgr*(pha>0), pha] for png_sequence output) fused with the writers' `frames.mul(255).byte()` and
  * NCHW->NHWC permute (inference_utils.py:44).  fgr [N,3,H,W], pha [N,1,H,W] in the given dtype
- * (RVM_DTYPE_F32: fp32 tensors, otherwise fp16) -> out uint8 [N,H,W,C], C = 4 for RGBA else 3.
+ * (RVM_DTYPE_F32: fp32 tensors, RVM_DTYPE_BF16IO: bf16, otherwise fp16) -> out uint8 [N,H,W,C], C = 4 for RGBA else 3.
  * Arithmetic is rounded to the tensor dtype op by op like the torch ops it replaces (bit-identical bytes). */
 enum { RVM_COMPOSE_GREEN = 0, RVM_COMPOSE_RGBA = 1, RVM_COMPOSE_ALPHA = 2, RVM_COMPOSE_FOREGROUND = 3 };
 int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_t* out, int N, int H, int W,

@@ -4,6 +4,26 @@
 #include <stdint.h>
 
 typedef _Float16 f16;
+// bfloat16 at the API boundary only (src, fgr, pha, r1..r4 of a .bfloat16() module): 1-8-7 bits, converted to / from
+// fp32 with round-to-nearest-even; arithmetic on it is done in fp32 and rounded per operation, like torch does.
+struct bf16 {
+    unsigned short v;
+    bf16() = default;
+    __host__ __device__ bf16(float f) {
+        unsigned u = __builtin_bit_cast(unsigned, f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { v = (unsigned short)((u >> 16) | 0x40u); return; }   // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        v = (unsigned short)(u >> 16);
+    }
+    __host__ __device__ operator float() const { return __builtin_bit_cast(float, (unsigned)v << 16); }
+};
+__host__ __device__ inline bf16 bf16_bits(unsigned short u) { bf16 b; b.v = u; return b; }
+__host__ __device__ inline bf16 operator*(bf16 a, bf16 b) { return bf16((float)a * (float)b); }
+__host__ __device__ inline bf16 operator+(bf16 a, bf16 b) { return bf16((float)a + (float)b); }
+__host__ __device__ inline bf16 operator-(bf16 a, bf16 b) { return bf16((float)a - (float)b); }
+__host__ __device__ inline bool operator>(bf16 a, bf16 b) { return (float)a > (float)b; }
+// element type of the tensors at the API boundary when it differs from the kernels' storage type
+enum IoMode { IO_SAME = 0, IO_F16 = 1, IO_BF16 = 2 };
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -84,6 +104,18 @@ struct ConvSrc {
     int f16;                                // fp16 tensor feeding an fp32 kernel
     int w0, nw;                             // conv_kxk: the waves [w0, w0 + nw) of a block stage this source (set by the launcher)
 };
+// 16-bit state tensors at the API (fp16 / bf16 module, fp32 arithmetic inside).  The context keeps the fp32 value of
+// every state it hands out (`shadow`); at the start of a frame each element of the incoming state is replaced by the
+// shadow value when that rounds to exactly what the caller passed (the caller handed our state straight back, the
+// normal recurrence) and taken as is otherwise (foreign / edited state).  Without this the state is re-rounded to
+// 16 bits every frame and stalls wherever the GRU's update is below half an ulp: a slow drift against the fp32
+// reference (measured: r2 4e-3 off after 140 HD frames).
+struct StatePrep {
+    const void* in[4]; const float* shadow[4]; float* out[4];   // per level: caller's state or null (zeros), kept fp32 state, fp32 state of this frame
+    int n[4];                                                   // elements per level (multiples of 4)
+    int blocks;                                                 // blocks of 1024 elements over the four levels; 0: none
+    int bf;                                                     // 16-bit type: 0 fp16, 1 bf16
+};
 enum ConvEpi { EPI_RELU = 0, EPI_GRU_IH = 1, EPI_GRU_HH = 2 };
 struct ConvArgs {
     ConvSrc src[4]; int nsrc; int Cpad;
@@ -97,8 +129,9 @@ struct ConvArgs {
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null
     void* rh; float* z;                     // GRU scratch [N][H][W][hC]
     void* hout;                             // GRU new state [N][H][W][hC]
-    void* hout2;                            // optional second copy of it (last step of a chunk: the caller's r_out)
+    void* hout2;                            // optional second copy of it (the caller's r_out)
     int state16;                            // hprev / hout are fp16 although the kernel computes in fp32
+    int out2_mode;                          // IoMode of hout2 (IO_SAME: like hout)
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
@@ -109,6 +142,8 @@ struct DownArgs {
     // fused encoder stem (mobilenetv3): normalize + conv3x3 s2 + BN + hardswish of the s0 block just formed; null: none
     void* stem_y; const float* stem_w /*[27][16]*/; const float* stem_b /*[16]*/;
     int Ho, Wo; float mean[3]; float std_[3];
+    int nblk;                               // blocks (x) of the downsample grid proper; the StatePrep blocks follow
+    StatePrep sp;
 };
 
 struct MaxPoolArgs { const void* x; void* y; int C, Hi, Wi, Ho, Wo; };
@@ -141,7 +176,7 @@ struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; voi
 // ---- output composition (driver step after forward) --------------------------------------------
 enum ComposeMode { COMPOSE_GREEN = 0, COMPOSE_RGBA = 1, COMPOSE_ALPHA = 2, COMPOSE_FOREGROUND = 3 };
 struct ComposeArgs { const void* fgr; const void* pha; unsigned char* out; int H, W, mode; float bgr[3]; };
-void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s);
+void launch_compose(const ComposeArgs& a, int N, int io, hipStream_t s);     // io: IO_SAME = fp32 tensors
 
 // ---- matting quality metrics (reference evaluation/evaluate_hr.py:176-235) ------------------------
 constexpr int METRIC_TILE = 32;             // output tile edge of matte_metrics
@@ -164,10 +199,10 @@ template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_
 template <typename T> void launch_gemv(const GemvArgs& a, int N, hipStream_t s);
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s);
 template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream_t s);
-template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s);
+template <typename T> void launch_down(const DownArgs& a, int N, int io, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
-template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s);
-template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s);
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, int io, hipStream_t s);
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, int io, hipStream_t s);
 template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK);
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s);
 size_t ed_lds_bytes(int K, int KS, int npxs, int es);

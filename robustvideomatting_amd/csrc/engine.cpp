@@ -190,7 +190,8 @@ struct FrameIO {
 
 struct rvm_ctx {
     int variant, refiner, dtype, device;
-    bool split = false;             // F16IO: GEMM operands as (hi, lo) fp16 pairs on the f16 MFMA (common.hpp f32s)
+    bool split = false;             // F16IO / BF16IO: GEMM operands as (hi, lo) fp16 pairs on the f16 MFMA (common.hpp f32s)
+    int iomode() const { return dtype == RVM_DTYPE_F16IO ? IO_F16 : (dtype == RVM_DTYPE_BF16IO ? IO_BF16 : IO_SAME); }
     std::vector<ParamSpec> specs;
     std::map<std::string, std::vector<float>> params;
     bool finalized = false;
@@ -679,7 +680,7 @@ int build_plan(rvm_ctx* c) {
     const int B = Bs * TT;
     const bool split = c->split;
     const size_t es = sizeof(T);
-    const int io16 = c->dtype == RVM_DTYPE_F16IO ? 1 : 0;   // fp16 tensors at the boundary, fp32 inside
+    const int io16 = c->iomode();                           // IO_F16 / IO_BF16: 16-bit tensors at the boundary, fp32 inside
     const size_t ies = c->dtype == RVM_DTYPE_F32 ? 4 : 2;   // element size of src / fgr / pha
     char* wb = c->wdev;
     const int* lh = c->lh; const int* lw = c->lw;
@@ -688,6 +689,27 @@ int build_plan(rvm_ctx* c) {
     auto add = [&](const std::string& name, double flops, double bytes, std::function<void(hipStream_t, const FrameIO&)> f, int edge = 0) {
         c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f), edge});
     };
+
+    // ---- recurrent state buffers.  16-bit I/O modes: the GRUs never read the caller's 16-bit tensors; the first launch
+    // turns them into fp32 (StatePrep, common.hpp: the fp32 value kept from the previous call where it rounds to what
+    // the caller passed) and every GRU output stays fp32 in the arena (hseq; the caller gets a rounded copy).  The kept
+    // value is simply the last time step's slot of hseq.
+    const int rch[4] = {c->dec[2] / 2, c->dec[1] / 2, c->dec[0] / 2, c->feat[3] / 2};     // channels of r1..r4
+    float* hin32[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* hseq32[4] = {nullptr, nullptr, nullptr, nullptr};
+    StatePrep sprep; memset(&sprep, 0, sizeof sprep);
+    if (io16) {
+        for (int r = 0; r < 4; ++r) {
+            const size_t per = (size_t)Bs * lh[r + 1] * lw[r + 1] * rch[r];
+            hin32[r] = fbuf(per);
+            hseq32[r] = fbuf(per * TT);
+            sprep.shadow[r] = hseq32[r] + per * (TT - 1);
+            sprep.out[r] = hin32[r];
+            sprep.n[r] = (int)per;
+            sprep.blocks += (int)((per + 1023) >> 10);
+        }
+        sprep.bf = io16 == IO_BF16;
+    }
 
     // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
     T* s[4];
@@ -712,7 +734,11 @@ int build_plan(rvm_ctx* c) {
         }
         add(stem_out ? "downsample_pyramid_stem" : "downsample_pyramid", 8.0 * B * c->h * c->w * 3 + 8.0 * B * pyr + sflops,
             (double)B * (c->h * c->w * (3 * taps * ies + 4 * es) + pyr * 4 * es) + sbytes,
-            [=](hipStream_t st, const FrameIO& io) { DownArgs b = a; b.src = io.src; launch_down<T>(b, B, io16, st); }, 1);
+            [=](hipStream_t st, const FrameIO& io) {
+                DownArgs b = a; b.src = io.src; b.sp = sprep;
+                for (int r = 0; r < 4; ++r) b.sp.in[r] = io.r_in[r];
+                launch_down<T>(b, B, io16, st);
+            }, 1);
         for (int l = 0; l < 4; ++l) c->taps["s" + std::to_string(l)] = Tap{s[l], B, lh[l], lw[l], 4, 4, false};
     }
 
@@ -844,10 +870,10 @@ int build_plan(rvm_ctx* c) {
                 const ConvSrc& S = probe.src[k];
                 px_bytes += (double)(S.up ? S.Hs * S.Ws : Hi * Wi) * S.C * (S.f16 ? 2 : es);
             }
-            const double opx = (double)Ho * Wo, ses_ = probe.state16 ? 2 : es;
+            const double opx = (double)Ho * Wo;
             if (epi == EPI_RELU) px_bytes += opx * L.Cout * es;
             else if (epi == EPI_GRU_IH) px_bytes += opx * probe.hC * (es + 4);                    // r*h and z out (h is a source)
-            else px_bytes += opx * probe.hC * (4 + ses_ + ses_);                                   // z and h in, h' out
+            else px_bytes += opx * probe.hC * (4 + es + es + (probe.out2_mode ? 2 : 0));          // z and h in, h' out (+ the caller's 16-bit copy)
         }
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout, (double)B * px_bytes + KK * L.Cin * L.Cout * es, fn);
         return 0;
@@ -1047,31 +1073,34 @@ int build_plan(rvm_ctx* c) {
 
     // ---- recurrent decoder (decoder.py:17-27)
     // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
-    const size_t ses = io16 ? 2 : es;               // element size of a state tensor
+    const size_t ses = es;                          // element size of a state inside the plan (16-bit API states never get here)
     char* hseq[4] = {nullptr, nullptr, nullptr, nullptr};   // T > 1: the T outputs of a level's GRU, [T][Bs][H][W][C]
     auto gru = [&](const std::string& name, const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
         const int C = G.C;
         const size_t per = (size_t)Bs * Hh * Ww;    // pixels of one time step
         T* rh = abuf(per * C);
         float* z = fbuf(per * C);
-        char* hs = TT > 1 ? (char*)c->arena_alloc((size_t)TT * per * C * ses) : nullptr;
+        // io16: fp32 states in the arena for every step (allocated above); else for chunks only, in the state's type
+        char* hs = io16 ? (char*)hseq32[ridx] : (TT > 1 ? (char*)c->arena_alloc((size_t)TT * per * C * ses) : nullptr);
         hseq[ridx] = hs;
+        const float* hin = hin32[ridx];
         for (int t = 0; t < TT; ++t) {
             const std::string nm = TT > 1 ? name + "[" + std::to_string(t) + "]" : name;
             const T* xt = xb + (size_t)t * per * xs;
-            const void* hp = t ? hs + (size_t)(t - 1) * per * C * ses : nullptr;      // nullptr: the caller's r_in
+            const void* hp = t ? hs + (size_t)(t - 1) * per * C * ses : nullptr;      // nullptr: the state coming in
             void* ho = hs ? hs + (size_t)t * per * C * ses : nullptr;                 // nullptr: the caller's r_out
             const bool last = t == TT - 1;
             if (conv3(nm + ".ih", G.ih, Hh, Ww, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
-                    const void* h = t ? hp : io.r_in[ridx];
-                    a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{h, C, C, 0, 0, 0, io16}; a.nsrc = 2;
-                    a.hprev = h; a.hC = C; a.rh = rh; a.z = z; a.state16 = io16;
+                    const void* h = t ? hp : (io16 ? (const void*)hin : io.r_in[ridx]);
+                    a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{h, C, C, 0, 0, 0, 0}; a.nsrc = 2;
+                    a.hprev = h; a.hC = C; a.rh = rh; a.z = z;
                 }, Bs)) return 1;
             if (conv3(nm + ".hh", G.hh, Hh, Ww, Hh, Ww, EPI_GRU_HH, [=](ConvArgs& a, const FrameIO& io) {
                     a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{rh, C, C, 0, 0, 0, 0}; a.nsrc = 2;
-                    a.hprev = t ? hp : io.r_in[ridx]; a.hC = C; a.z = z; a.state16 = io16;
+                    a.hprev = t ? hp : (io16 ? (const void*)hin : io.r_in[ridx]); a.hC = C; a.z = z;
                     a.hout = ho ? ho : io.r_out[ridx];
                     a.hout2 = (ho && last) ? io.r_out[ridx] : nullptr;                 // the state handed back
+                    a.out2_mode = io16;
                 }, Bs)) return 1;
         }
         return 0;
@@ -1093,7 +1122,7 @@ int build_plan(rvm_ctx* c) {
         const char* hs_ = hseq[hidx];
         if (conv3("decode" + std::to_string(l) + ".conv", c->up[i], lh[l], lw[l], lh[l], lw[l], EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
-                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[hidx], xaC_, xaC_, 1, Hs, Ws, 0};
                 a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0, 0};
                 a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 4; a.y = X; a.ys = Cout;
@@ -1116,7 +1145,7 @@ int build_plan(rvm_ctx* c) {
         const char* hs_ = hseq[0];
         if (conv3("decode0.conv0", c->out0, c->h, c->w, c->h, c->w, EPI_RELU, [=](ConvArgs& a, const FrameIO& io) {
                 a.src[0] = ConvSrc{xa_, xaC_, xaS_, 1, Hs, Ws, 0};
-                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[0], xaC_, xaC_, 1, Hs, Ws, io16};
+                a.src[1] = ConvSrc{hs_ ? (const void*)hs_ : io.r_out[0], xaC_, xaC_, 1, Hs, Ws, 0};
                 a.src[2] = ConvSrc{s0, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 3; a.y = hidA; a.ys = HC;
             })) return 1;
@@ -1299,7 +1328,7 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     *out = nullptr;
     if (variant != RVM_VARIANT_MOBILENETV3 && variant != RVM_VARIANT_RESNET50) return fail("rvm_create: bad variant");
     if (refiner != RVM_REFINER_DEEP_GUIDED_FILTER && refiner != RVM_REFINER_FAST_GUIDED_FILTER) return fail("rvm_create: bad refiner");
-    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO) return fail("rvm_create: bad dtype");
+    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO && dtype != RVM_DTYPE_BF16IO) return fail("rvm_create: bad dtype");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("rvm_create: no such HIP device");
@@ -1308,7 +1337,7 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     if (device < 64 && !inited[device]) { kernels_init(); inited[device] = true; }
     rvm_ctx* c = new rvm_ctx();
     c->variant = variant; c->refiner = refiner; c->dtype = dtype; c->device = device;
-    if (dtype == RVM_DTYPE_F16IO) {
+    if (dtype == RVM_DTYPE_F16IO || dtype == RVM_DTYPE_BF16IO) {
         const char* e = getenv("RVM_F16IO_MFMA");               // "f32": exact fp32 MFMA instead of the f16 split
         c->split = !(e && std::string(e) == "f32");
     }
@@ -1478,12 +1507,12 @@ int rvm_compose_u8(int dtype, int mode, const void* fgr, const void* pha, uint8_
     if (!pha || !out || (mode != RVM_COMPOSE_ALPHA && !fgr)) return fail("rvm_compose_u8: null buffer");
     if (mode < 0 || mode > 3) return fail("rvm_compose_u8: bad mode");
     if (N < 1 || H < 1 || W < 1) return fail("rvm_compose_u8: bad shape");
-    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO) return fail("rvm_compose_u8: bad dtype");
+    if (dtype != RVM_DTYPE_F32 && dtype != RVM_DTYPE_F16 && dtype != RVM_DTYPE_F16IO && dtype != RVM_DTYPE_BF16IO) return fail("rvm_compose_u8: bad dtype");
     if (mode == RVM_COMPOSE_GREEN && !bgr) return fail("rvm_compose_u8: background colour missing");
     ComposeArgs a; memset(&a, 0, sizeof a);
     a.fgr = fgr; a.pha = pha; a.out = out; a.H = H; a.W = W; a.mode = mode;
     for (int k = 0; k < 3; ++k) a.bgr[k] = bgr ? bgr[k] : 0.f;
-    launch_compose(a, N, dtype != RVM_DTYPE_F32, (hipStream_t)hip_stream);
+    launch_compose(a, N, dtype == RVM_DTYPE_F32 ? IO_SAME : (dtype == RVM_DTYPE_BF16IO ? IO_BF16 : IO_F16), (hipStream_t)hip_stream);
     HIPCHK(hipGetLastError());
     return 0;
 }

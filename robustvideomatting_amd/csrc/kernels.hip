@@ -91,12 +91,22 @@ __device__ __forceinline__ void stp4(f32s* row, int c, f32x4 v) {
     *(f16x4*)(g + 8) = lo;
 }
 
-// element-typed access through a runtime flag (fp16 tensors at the API boundary of the mixed mode)
-__device__ __forceinline__ f32x4 ld4x(const void* p, size_t i, bool half) {
-    return half ? ld4f((const f16*)p + i) : ld4f((const float*)p + i);
+// bf16 <-> fp32, four at a time (round-to-nearest-even like bf16's constructor)
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4f(const bf16* p) {
+    const u16x4 u = *(const u16x4*)p;
+    return f32x4{(float)bf16_bits(u[0]), (float)bf16_bits(u[1]), (float)bf16_bits(u[2]), (float)bf16_bits(u[3])};
 }
-__device__ __forceinline__ void st4x(void* p, size_t i, bool half, f32x4 v) {
-    if (half) st4f((f16*)p + i, v); else st4f((float*)p + i, v);
+__device__ __forceinline__ void st4f(bf16* p, f32x4 v) {
+    *(u16x4*)p = u16x4{bf16(v[0]).v, bf16(v[1]).v, bf16(v[2]).v, bf16(v[3]).v};
+}
+// element-typed access through a runtime mode (16-bit tensors at the API boundary of the mixed modes):
+// 0 / false = fp32, 1 / true = fp16, 2 = bf16 (IoMode)
+__device__ __forceinline__ f32x4 ld4x(const void* p, size_t i, int mode) {
+    return mode == 1 ? ld4f((const f16*)p + i) : (mode == 2 ? ld4f((const bf16*)p + i) : ld4f((const float*)p + i));
+}
+__device__ __forceinline__ void st4x(void* p, size_t i, int mode, f32x4 v) {
+    if (mode == 1) st4f((f16*)p + i, v); else if (mode == 2) st4f((bf16*)p + i, v); else st4f((float*)p + i, v);
 }
 
 // MFMA operand fragments: 8 K-elements per lane.
@@ -1216,7 +1226,7 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
                 st4x(a.hout, pix * a.hC + c, sizeof(T) == 2 || a.state16, cv);
-                if (a.hout2) st4x(a.hout2, pix * a.hC + c, sizeof(T) == 2 || a.state16, cv);
+                if (a.hout2) st4x(a.hout2, pix * a.hC + c, a.out2_mode ? a.out2_mode : (int)(sizeof(T) == 2 || a.state16), cv);
             }
         }
     }
@@ -1468,7 +1478,7 @@ __global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
             st4x(a.hout, pix * a.hC + c, s16, cv);
-            if (a.hout2) st4x(a.hout2, pix * a.hC + c, s16, cv);
+            if (a.hout2) st4x(a.hout2, pix * a.hC + c, a.out2_mode ? a.out2_mode : (int)s16, cv);
         }
     }
     stamp(2);
@@ -1525,9 +1535,39 @@ __device__ __forceinline__ float quad_lane(float v, int k) {        // value of 
     }
     return __builtin_bit_cast(float, r);
 }
+// StatePrep (common.hpp): blocks beyond the downsample grid turn the caller's 16-bit states into this frame's fp32
+// states - element by element the kept fp32 value where it rounds to what the caller passed, else the caller's value.
+template <typename T16>
+__device__ __forceinline__ void state_prep(const StatePrep& sp, int blk, int tid) {
+    int l = 0, b0 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int nb = (sp.n[k] + 1023) >> 10;
+        if (l == k && blk >= b0 + nb) { l = k + 1; b0 += nb; }
+    }
+    const int n = l == 0 ? sp.n[0] : (l == 1 ? sp.n[1] : (l == 2 ? sp.n[2] : sp.n[3]));
+    const void* in = l == 0 ? sp.in[0] : (l == 1 ? sp.in[1] : (l == 2 ? sp.in[2] : sp.in[3]));
+    const float* sh = l == 0 ? sp.shadow[0] : (l == 1 ? sp.shadow[1] : (l == 2 ? sp.shadow[2] : sp.shadow[3]));
+    float* out = l == 0 ? sp.out[0] : (l == 1 ? sp.out[1] : (l == 2 ? sp.out[2] : sp.out[3]));
+    const int i = ((blk - b0) << 10) + tid * 4;
+    if (i >= n) return;
+    f32x4 v = f32x4{0, 0, 0, 0};
+    if (in) {
+        const f32x4 h = ld4f((const T16*)in + i), k = *(const f32x4*)(sh + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((float)(T16)k[r] == h[r]) ? k[r] : h[r];
+    }
+    *(f32x4*)(out + i) = v;
+}
 template <typename T, typename TIO, bool STEM>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
+    if constexpr (sizeof(TIO) == 2 && sizeof(T) == 4) {
+        if ((int)blockIdx.x >= a.nblk) {                             // whole block
+            if (blockIdx.y == 0) state_prep<TIO>(a.sp, (int)blockIdx.x - a.nblk, threadIdx.x);
+            return;
+        }
+    }
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, n = blockIdx.y;
     if (wv >= a.h3 * a.w3) return;                                   // whole wave
     const int y3 = wv / a.w3, x3 = wv - y3 * a.w3;
@@ -1673,18 +1713,28 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         }
     }
 }
-template <typename T> void launch_down(const DownArgs& a, int N, bool io16, hipStream_t s) {
-    const dim3 grid((a.h3 * a.w3 + 3) / 4, N);
-    if (a.stem_y) {
-        if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((downsample<T, T, true>), grid, dim3(256), 0, s, a);
-    } else {
-        if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((downsample<T, f16, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((downsample<T, T, false>), grid, dim3(256), 0, s, a);
+template <typename T> void launch_down(const DownArgs& a_, int N, int io, hipStream_t s) {
+    DownArgs a = a_;
+    a.nblk = (a.h3 * a.w3 + 3) / 4;
+    if (sizeof(T) != 4 || !io) a.sp.blocks = 0;
+    const dim3 grid(a.nblk + a.sp.blocks, N);
+    if constexpr (sizeof(T) == 4) {
+        if (io == IO_F16) {
+            if (a.stem_y) hipLaunchKernelGGL((downsample<T, f16, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((downsample<T, f16, false>), grid, dim3(256), 0, s, a);
+            return;
+        }
+        if (io == IO_BF16) {
+            if (a.stem_y) hipLaunchKernelGGL((downsample<T, bf16, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((downsample<T, bf16, false>), grid, dim3(256), 0, s, a);
+            return;
+        }
     }
+    if (a.stem_y) hipLaunchKernelGGL((downsample<T, T, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((downsample<T, T, false>), grid, dim3(256), 0, s, a);
 }
-template void launch_down<f16>(const DownArgs&, int, bool, hipStream_t);
-template void launch_down<float>(const DownArgs&, int, bool, hipStream_t);
+template void launch_down<f16>(const DownArgs&, int, int, hipStream_t);
+template void launch_down<float>(const DownArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Refiner, low-res half: project_mat 1x1 (model.py:62) + guided-filter statistics with the
@@ -2041,9 +2091,23 @@ template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
 // 37-39), out = A*[src,gray]+b (:41), fgr = clamp(out+src), pha = clamp(out) (model.py:65-67).
 // One pass: src read once, fgr/pha written once; a thread owns 8 consecutive x.
 // ------------------------------------------------------------------------------------------
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 template <typename TIO> struct IoV8;
-template <> struct IoV8<f16> { typedef f16x8 type; };
-template <> struct IoV8<float> { typedef f32x8 type; };
+template <> struct IoV8<f16> {
+    typedef f16x8 type;
+    static __device__ __forceinline__ float get(const f16x8& v, int j) { return (float)v[j]; }
+    static __device__ __forceinline__ void set(f16x8& v, int j, f16 e) { v[j] = e; }
+};
+template <> struct IoV8<float> {
+    typedef f32x8 type;
+    static __device__ __forceinline__ float get(const f32x8& v, int j) { return v[j]; }
+    static __device__ __forceinline__ void set(f32x8& v, int j, float e) { v[j] = e; }
+};
+template <> struct IoV8<bf16> {
+    typedef u16x8 type;
+    static __device__ __forceinline__ float get(const u16x8& v, int j) { return (float)bf16_bits(v[j]); }
+    static __device__ __forceinline__ void set(u16x8& v, int j, bf16 e) { v[j] = e.v; }
+};
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 8 output values of one channel, packed to the I/O type pair by pair as they are produced
@@ -2053,6 +2117,12 @@ template <> struct Out8<f16> {
     __device__ __forceinline__ void set(int jp, float a, float b) { f16x2 p = {(f16)a, (f16)b}; r[jp] = __builtin_bit_cast(unsigned, p); }
     __device__ __forceinline__ void store(f16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
     __device__ __forceinline__ f16 get(int j) const { return __builtin_bit_cast(f16x2, r[j >> 1])[j & 1]; }
+};
+template <> struct Out8<bf16> {
+    unsigned r[4];
+    __device__ __forceinline__ void set(int jp, float a, float b) { r[jp] = (unsigned)bf16(a).v | ((unsigned)bf16(b).v << 16); }
+    __device__ __forceinline__ void store(bf16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
+    __device__ __forceinline__ bf16 get(int j) const { return bf16_bits((unsigned short)(r[j >> 1] >> (16 * (j & 1)))); }
 };
 template <> struct Out8<float> {
     float r[8];
@@ -2085,7 +2155,11 @@ __global__ __launch_bounds__(256, 6) void dgf_apply(DgfApplyArgs a) {      // <=
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[c][j] = (active && x0 + j < a.W) ? sp[c * plane + j] : (TIO)0;
+            for (int j = 0; j < 8; ++j) {
+                TIO e = (TIO)0.f;
+                if (active && x0 + j < a.W) e = sp[c * plane + j];
+                IoV8<TIO>::set(s[c], j, e);
+            }
     }
     // ---- vertical interpolation of the columns this segment needs
     float sy = a.scale_y * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
@@ -2136,7 +2210,7 @@ __global__ __launch_bounds__(256, 6) void dgf_apply(DgfApplyArgs a) {      // <=
             const int k0 = min(ix0 - cbase, a.ncols - 1), k1 = min(ix1 - cbase, a.ncols - 1);
             const f32x4 A = (1.f - lx) * colAB[2 * k0] + lx * colAB[2 * k1];
             const f32x4 B = (1.f - lx) * colAB[2 * k0 + 1] + lx * colAB[2 * k1 + 1];
-            const float sr = (float)s[0][j], sg = (float)s[1][j], sb = (float)s[2][j];
+            const float sr = IoV8<TIO>::get(s[0], j), sg = IoV8<TIO>::get(s[1], j), sb = IoV8<TIO>::get(s[2], j);
             const float gray = (sr + sg + sb) / 3.f;
             o[e][0] = fminf(fmaxf(A[0] * sr + B[0] + sr, 0.f), 1.f);
             o[e][1] = fminf(fmaxf(A[1] * sg + B[1] + sg, 0.f), 1.f);
@@ -2164,14 +2238,15 @@ __global__ __launch_bounds__(256, 6) void dgf_apply(DgfApplyArgs a) {      // <=
         }
     }
 }
-template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, bool io16, hipStream_t s) {
+template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, int io, hipStream_t s) {
     const dim3 grid((a.W + 2047) / 2048, a.H, N);
     const size_t lds = (size_t)a.ncols * 32;
-    if (sizeof(T) == 2 || io16) hipLaunchKernelGGL((dgf_apply<f16>), grid, dim3(256), lds, s, a);
+    if (sizeof(T) == 2 || io == IO_F16) hipLaunchKernelGGL((dgf_apply<f16>), grid, dim3(256), lds, s, a);
+    else if (io == IO_BF16) hipLaunchKernelGGL((dgf_apply<bf16>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((dgf_apply<float>), grid, dim3(256), lds, s, a);
 }
-template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, bool, hipStream_t);
-template void launch_dgf_apply<float>(const DgfApplyArgs&, int, bool, hipStream_t);
+template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, int, hipStream_t);
+template void launch_dgf_apply<float>(const DgfApplyArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // downsample_ratio == 1 tail (no refiner): project_mat + residual + clamp (model.py:62,65-67)
@@ -2210,12 +2285,14 @@ __global__ __launch_bounds__(256) void proj_out(ProjOutArgs a) {
     for (int c = 0; c < 3; ++c) fp[(size_t)c * HW] = (TIO)fminf(fmaxf(y[c] + (float)sp[(size_t)c * HW], 0.f), 1.f);
     ((TIO*)a.pha)[(size_t)n * HW + p] = (TIO)fminf(fmaxf(y[3], 0.f), 1.f);
 }
-template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, bool io16, hipStream_t s) {
-    if (sizeof(T) == 4 && io16) hipLaunchKernelGGL((proj_out<T, f16>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((proj_out<T, T>), dim3((a.H * a.W + 255) / 256, N), dim3(256), 0, s, a);
+template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, int io, hipStream_t s) {
+    const dim3 grid((a.H * a.W + 255) / 256, N);
+    if (sizeof(T) == 4 && io == IO_F16) hipLaunchKernelGGL((proj_out<T, f16>), grid, dim3(256), 0, s, a);
+    else if (sizeof(T) == 4 && io == IO_BF16) hipLaunchKernelGGL((proj_out<T, bf16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((proj_out<T, T>), grid, dim3(256), 0, s, a);
 }
-template void launch_proj_out<f16>(const ProjOutArgs&, int, bool, hipStream_t);
-template void launch_proj_out<float>(const ProjOutArgs&, int, bool, hipStream_t);
+template void launch_proj_out<f16>(const ProjOutArgs&, int, int, hipStream_t);
+template void launch_proj_out<float>(const ProjOutArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Output step of the reference driver on the device (inference.py:116,137-141 and the writers'
@@ -2264,9 +2341,10 @@ __global__ __launch_bounds__(256) void compose_u8(ComposeArgs a) {
     }
     if (a.mode == COMPOSE_RGBA) o[3] = to_byte<TIO>(al);
 }
-void launch_compose(const ComposeArgs& a, int N, bool io16, hipStream_t s) {
+void launch_compose(const ComposeArgs& a, int N, int io, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)a.H * a.W + 255) / 256), N);
-    if (io16) hipLaunchKernelGGL((compose_u8<f16>), grid, dim3(256), 0, s, a);
+    if (io == IO_F16) hipLaunchKernelGGL((compose_u8<f16>), grid, dim3(256), 0, s, a);
+    else if (io == IO_BF16) hipLaunchKernelGGL((compose_u8<bf16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((compose_u8<float>), grid, dim3(256), 0, s, a);
 }
 
@@ -2443,6 +2521,7 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<float>());
     (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)dgf_apply<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 #define RVM_ED_ATTR(TT, KK) \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \

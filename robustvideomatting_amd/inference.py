@@ -111,11 +111,11 @@ def _video_unavailable(what):
 # ------------------------------------------------------------------------------------------ device output step
 def compose_u8(fgr, pha, mode, bgr=None):
     """fgr [T,3,H,W], pha [T,1,H,W] device tensors -> uint8 [T,H,W,C] device tensor (rvm_compose_u8)."""
-    assert pha.is_cuda and pha.is_contiguous() and pha.dtype in (torch.float32, torch.float16)
+    assert pha.is_cuda and pha.is_contiguous() and pha.dtype in (torch.float32, torch.float16, torch.bfloat16)
     T, _, H, W = pha.shape
     C = 4 if mode == native.COMPOSE_RGBA else 3
     out = torch.empty((T, H, W, C), device=pha.device, dtype=torch.uint8)
-    code = native.DTYPE_F32 if pha.dtype == torch.float32 else native.DTYPE_F16IO
+    code = {torch.float32: native.DTYPE_F32, torch.float16: native.DTYPE_F16IO, torch.bfloat16: native.DTYPE_BF16IO}[pha.dtype]
     fptr = 0
     if mode != native.COMPOSE_ALPHA:
         assert fgr.is_contiguous() and fgr.dtype == pha.dtype and fgr.shape == (T, 3, H, W)

@@ -165,8 +165,10 @@ class MattingNetwork(nn.Module):
             if self.fp16_arithmetic not in ("fp32", "fp16"):
                 raise RuntimeError("fp16_arithmetic must be 'fp32' or 'fp16'")
             code = native.DTYPE_F16IO if self.fp16_arithmetic == "fp32" else native.DTYPE_F16
+        elif dtype == torch.bfloat16:
+            code = native.DTYPE_BF16IO      # bf16 tensors at the boundary, fp32-accurate arithmetic inside
         else:
-            raise RuntimeError("MattingNetwork (MI355X): unsupported dtype %s (float32 / float16)" % dtype)
+            raise RuntimeError("MattingNetwork (MI355X): unsupported dtype %s (float32 / float16 / bfloat16)" % dtype)
         key = (device.index if device.index is not None else torch.cuda.current_device(), code)
         if self._ctx is None or self._ctx_key != key:
             if self._ctx is not None:

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("RVM_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, "lib", "librvm_mi355x%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
-DTYPE_F32, DTYPE_F16, DTYPE_F16IO = 0, 1, 2
+DTYPE_F32, DTYPE_F16, DTYPE_F16IO, DTYPE_BF16IO = 0, 1, 2, 3
 VARIANTS = {"mobilenetv3": 0, "resnet50": 1}
 REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 

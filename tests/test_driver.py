@@ -59,7 +59,7 @@ def test_oracle_frames_to_u8_truncates():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_compose_kernel_bytes_equal_reference_ops(dtype):
     from robustvideomatting_amd import native
     g = torch.Generator().manual_seed(3)

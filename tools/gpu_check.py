@@ -18,8 +18,8 @@ TAPS = ["s0", "s1", "s2", "s3", "f1", "f2", "f3", "f4", "aspp", "x3", "x2", "x1"
 
 def run(dtype="fp32", H=122, W=218, ds=0.25, T=3, B=1, variant="mobilenetv3", refiner="deep_guided_filter",
         seed=0, verbose=True, graph=False, noise=0.04):
-    # dtype: fp32 | fp16 (fp16 tensors, fp32 arithmetic inside) | fp16fast (fp16 storage + fp16 MFMA)
-    tdt = torch.float32 if dtype == "fp32" else torch.float16
+    # dtype: fp32 | fp16 (fp16 tensors, fp32 arithmetic inside) | fp16fast (fp16 storage + fp16 MFMA) | bf16 (bf16 tensors, fp32 inside)
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(dtype, torch.float16)
     params = synthetic.make_params(variant, refiner, seed=seed, perturb_box_filter=True)
     model = MattingNetwork(variant, refiner).eval()
     model.load_state_dict(params)
