@@ -81,6 +81,7 @@ struct EdArgs {
     const float* fc1_w; int S; float* hpart;// SE: fc1 weights [S][C] (fp32), partial pre-activations [N][nparts][S]; or null
     int C, Hi, Wi, Ho, Wo, stride, dil, pad;
     int rb, nband;                          // output rows per band, number of bands
+    int cwt, ncol;                          // output columns per column tile and their number (ncol <= 1: full-width bands)
     int cw;                                 // channels per block: 16, or 8 (already expanded input only)
     int npxs;                               // pixels per channel-quad plane of the LDS tile (>= rows*Wi of any band, multiple of 16)
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production

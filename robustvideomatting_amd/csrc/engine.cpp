@@ -907,7 +907,16 @@ int build_plan(rvm_ctx* c) {
                 auto rows_for = [&](int rb) { return std::min(Hi, (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1); };
                 const int KS = b.has_expand ? b.expand.KS : 0;
                 auto trows_for = [&](int rb) { return (rb - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1; };      // zero-padded tile rows
-                auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16), (int)es); };
+                // Column tiles: a full-width LDS tile of the widest layers does not fit for low-res frames wider than
+                // ~1800 px (1080p at ds = 1, 4K at ds = 0.5); the tile then covers `cwt` output columns plus the halo.
+                int cwt = Wo, ncol = 1;
+                if (const char* e = getenv("RVM_ED_CWT")) {                 // test hook: force column tiles on small frames
+                    const int v = atoi(e);
+                    if (v >= 4 && v < Wo) { cwt = v; ncol = cdiv(Wo, cwt); }
+                }
+                auto tcols_for = [&](int cw_) { return cw_ >= Wo ? Wi + 2 * b.dw.pad : (cw_ - 1) * b.dw.stride + (K - 1) * b.dw.dil + 1; };
+                auto tin_for = [&](int cw_) { return std::min(Wi, tcols_for(cw_)); };                           // real input columns of a tile
+                auto lds_for = [&](int rb) { return ed_lds_bytes(K, KS, rup(trows_for(rb) * tcols_for(cwt), 16), (int)es); };
                 // Rows per band: the 1024-thread blocks run one per CU, so the launch takes
                 // ceil(blocks / 256) rounds of (tile rows) work each; pick the band height that minimises
                 // rounds x tile rows with the tile inside LDS.  SE layers keep <= 256 partial rows for the
@@ -916,16 +925,21 @@ int build_plan(rvm_ctx* c) {
                 const int se_parts = 256;       // partial rows the squeeze-excite gemv sums per sample (measured: 64 / 128 / 256 -> 2275 / 2283 / 2290 fps)
                 {
                     int valid[16], nvalid = 0, model = -1;
-                    double best = 1e30;
-                    for (int cand = Ho; cand >= 1 && nvalid < 16; cand = cand > 1 ? cdiv(cand, 2) : 0) {
-                        const int bands = cdiv(Ho, cand);
-                        if (lds_for(cand) > 150 * 1024 || rup(cand * Wo, 64) > 4096 || rows_for(cand) * Wi >= 65536) continue;
-                        if (b.has_se && nslice * bands > se_parts && cand != Ho) continue;
-                        const double cost = (double)cdiv(nslice * bands * B, 256) * (trows_for(cand) + 2);   // + fixed per-block part
-                        if (cost < best - 1e-9) { best = cost; model = nvalid; }
-                        valid[nvalid++] = cand;
+                    for (;;) {
+                        double best = 1e30;
+                        for (int cand = Ho; cand >= 1 && nvalid < 16; cand = cand > 1 ? cdiv(cand, 2) : 0) {
+                            const int bands = cdiv(Ho, cand);
+                            if (lds_for(cand) > 150 * 1024 || rup(cand * std::min(cwt, Wo), 64) > 4096 || rows_for(cand) * tin_for(cwt) >= 65536) continue;
+                            if (b.has_se && ncol == 1 && nslice * bands > se_parts && cand != Ho) continue;
+                            const double cost = (double)cdiv(nslice * bands * ncol * B, 256) * (trows_for(cand) + 2);   // + fixed per-block part
+                            if (cost < best - 1e-9) { best = cost; model = nvalid; }
+                            valid[nvalid++] = cand;
+                        }
+                        if (nvalid > 0 || cwt <= 8) break;
+                        cwt = cdiv(cwt, 2); ncol = cdiv(Wo, cwt);         // nothing fits at this width: halve the column tile
                     }
                     if (nvalid == 0) return fail("mbconv_ed: tile does not fit LDS");
+                    if ((int64_t)cdiv(Ho, 1) * ncol > 65535) return fail("mbconv_ed: frame too large for the grid");
                     rb = valid[tune_pick("mb" + std::to_string(i + 1) + ".ed", nvalid, model)];
                 }
                 EdArgs a; memset(&a, 0, sizeof a);
@@ -934,7 +948,7 @@ int build_plan(rvm_ctx* c) {
                 // only ~30-70 GB/s, so when that is more than ~160 KB per block (the 5x5 dilated layers at
                 // 1/16 scale, whose halo forbids bands) the expand runs as its own full-chip GEMM instead and
                 // the fused kernel starts from the expanded tensor (16-channel slices, no redundancy).
-                const size_t xbytes = (size_t)rows_for(rb) * Wi * curC * es;
+                const size_t xbytes = (size_t)rows_for(rb) * tin_for(cwt) * curC * es;
                 bool fuse_e = b.has_expand && b.expand.KS <= 3 && !(xbytes > 160 * 1024 && !getenv("RVM_ED_ALWAYS_FUSE"));
                 if (b.has_expand && !fuse_e) {
                     T* e = abuf((size_t)B * Hi * Wi * exp);
@@ -947,14 +961,15 @@ int build_plan(rvm_ctx* c) {
                 pj_done = pj_out;
                 if (b.pj) { a.pj_w = (const float*)(wb + b.pj_w); a.pj_b = (const float*)(wb + b.pj_b); }
                 a.y = b.pj ? pj_out : dwo; a.C = exp; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride; a.dil = b.dw.dil; a.pad = b.dw.pad;
-                a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(trows_for(rb) * (Wi + 2 * b.dw.pad), 16);
+                a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(trows_for(rb) * tcols_for(cwt), 16);
+                a.cwt = cwt; a.ncol = ncol;
                 { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
-                if (a.KS > 3 || rup(rb * Wo, 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * Wi >= 65536 || (b.has_se && b.se.S > 1024))
+                if (a.KS > 3 || rup(rb * std::min(cwt, Wo), 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * tin_for(cwt) >= 65536 || (b.has_se && b.se.S > 1024))
                     return fail("mbconv_ed: unsupported block shape");
                 // an already expanded layer with few 16-channel blocks (the 1/16-scale layers: <= 60 on 256 CUs) splits
                 // into 8-channel blocks: half the depthwise work per block, twice the CUs
-                a.cw = (!fuse_e && b.has_expand && exp % 8 == 0 && nslice * a.nband * B <= 128) ? 8 : 16;
-                const int nparts = cdiv(exp, a.cw) * a.nband;
+                a.cw = (!fuse_e && b.has_expand && exp % 8 == 0 && nslice * a.nband * ncol * B <= 128) ? 8 : 16;
+                const int nparts = cdiv(exp, a.cw) * a.nband * ncol;
                 float* hpart = nullptr;
                 if (b.has_se) {
                     hpart = fbuf((size_t)B * nparts * b.se.S);

@@ -506,15 +506,22 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int slice = blockIdx.x, band = blockIdx.y, n = blockIdx.z;
+    // blockIdx.y = band x column tile (column tiles: frames too wide for a full-width LDS tile)
+    const int ncol = a.ncol > 1 ? a.ncol : 1;
+    const int slice = blockIdx.x, band = (int)blockIdx.y / ncol, ctile = (int)blockIdx.y - band * ncol, n = blockIdx.z;
+    const int ox0 = ncol > 1 ? ctile * a.cwt : 0, ox1 = ncol > 1 ? min(ox0 + a.cwt, a.Wo) : a.Wo;   // output columns of this tile
+    const int TWo = ox1 - ox0;
     // a block owns a.cw channels: 16, or 8 for the already expanded layers whose grid would leave CUs idle
     const int c0 = slice * a.cw, cend = min(a.C, c0 + a.cw), nq = a.cw >> 2, nqlog = a.cw == 8 ? 1 : 2;
     const int r0 = band * a.rb, r1 = min(r0 + a.rb, a.Ho);
     const int t_lo = r0 * a.stride - a.pad;                          // input row of tile row 0 (may be negative)
     const int trows = (r1 - r0 - 1) * a.stride + (K - 1) * a.dil + 1;
     const int in_lo = max(t_lo, 0), in_hi = min(t_lo + trows - 1, a.Hi - 1);
-    const int NPX = (in_hi - in_lo + 1) * a.Wi;                      // real input pixels of the band (contiguous)
-    const int PWt = a.Wi + 2 * a.pad;
+    const int tc_lo = ox0 * a.stride - a.pad;                        // input column of tile column 0 (may be negative)
+    const int PWt = (TWo - 1) * a.stride + (K - 1) * a.dil + 1;      // padded tile width
+    const int ic_lo = max(tc_lo, 0), ic_hi = min(tc_lo + PWt - 1, a.Wi - 1);
+    const int TWi = ic_hi - ic_lo + 1;                               // real input columns of the tile
+    const int NPX = (in_hi - in_lo + 1) * TWi;                       // real input pixels of the tile (rows of TWi)
     f32x4* ebuf = (f32x4*)smem;                                      // [4][npxs]
     T* we = (T*)(ebuf + 4 * a.npxs);                                 // [KS][512]
     float* wd = (float*)(we + (size_t)a.KS * 512);                   // [K*K][16]
@@ -522,11 +529,18 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     float* be = bd + 16;                                             // [16]
     float* psum = be + 16;                                           // [16]
     f32x4* red = (f32x4*)(psum + 16);                                // [<= 256] per-wave-item partial sums
-    const T* xb = (const T*)a.x + ((size_t)n * a.Hi + in_lo) * a.Wi * a.xs;
-    const unsigned invW = 0xFFFFFFFFu / (unsigned)a.Wi + 1u;         // px / Wi == umulhi(px, invW) for px < 2^16
-    auto tile_index = [&](int px) {                                  // flat band pixel -> padded tile index
-        const int iy = (int)__umulhi((unsigned)px, invW), ix = px - iy * a.Wi;
-        return (in_lo - t_lo + iy) * PWt + ix + a.pad;
+    const T* xb = (const T*)a.x + (((size_t)n * a.Hi + in_lo) * a.Wi + ic_lo) * a.xs;
+    const unsigned invW = TWi > 1 ? 0xFFFFFFFFu / (unsigned)TWi + 1u : 0u;    // px / TWi == umulhi(px, invW) for px < 2^16 (TWi == 1: see fdiv)
+    auto fdiv = [](int p, unsigned inv) { return inv ? (int)__umulhi((unsigned)p, inv) : p; };   // inv == 0 <=> divisor 1
+    const bool fullw = TWi == a.Wi;                                  // the tile's input rows are one contiguous pixel range
+    auto tile_index = [&](int px) {                                  // flat tile pixel -> padded tile index
+        const int iy = fdiv(px, invW), ix = px - iy * TWi;
+        return (in_lo - t_lo + iy) * PWt + ix + (ic_lo - tc_lo);
+    };
+    auto src_index = [&](int px) {                                   // flat tile pixel -> pixel offset from xb
+        if (fullw) return px;
+        const int iy = fdiv(px, invW), ix = px - iy * TWi;
+        return iy * a.Wi + ix;
     };
 
     // ---- E: expand into the LDS tile.  The first m-tile's pixel loads are issued before the weights are
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     auto load_x = [&](int mt, XRaw<T>* xf) {
         const int px = mt * 16 + l15;
         const bool pv = px < NPX;
-        const T* xp = xb + (size_t)(pv ? px : 0) * a.xs + g * 8;
+        const T* xp = xb + (size_t)(pv ? src_index(px) : 0) * a.xs + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KSN; ++ks) {                           // branch-free loads
             const bool ok = pv && ks * 32 + g * 8 < a.Cin;
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
             for (int u = 0; u < 4; ++u) {
                 const int it = it0 + u * 1024, px = it >> nqlog, q = it & (nq - 1);
                 const bool ok = it < NPX * nq && c0 + q * 4 < cend;
-                v[u] = ld4f(xb + (ok ? (size_t)px * a.xs + c0 + q * 4 : 0));
+                v[u] = ld4f(xb + (ok ? (size_t)src_index(px) * a.xs + c0 + q * 4 : 0));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -632,11 +646,11 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
 
     stamp(2);
     // ---- D: depthwise conv out of the tile
-    const int npo = (r1 - r0) * a.Wo;
+    const int npo = (r1 - r0) * TWo;
     const int npo_pad = (npo + 63) & ~63;
     const int wpq = npo_pad >> 6;                                    // wave-items per channel quad
-    T* yb = (T*)a.y + ((size_t)n * a.Ho + r0) * a.Wo * a.C;
-    const unsigned invWo = 0xFFFFFFFFu / (unsigned)a.Wo + 1u;
+    T* yb = (T*)a.y + (((size_t)n * a.Ho + r0) * a.Wo + ox0) * a.C;
+    const unsigned invWo = TWo > 1 ? 0xFFFFFFFFu / (unsigned)TWo + 1u : 0u;
     const int rowstep = a.dil * PWt;
     if constexpr (PJ) {
         // Block 1 (mobilenetv3.py features[1]: depthwise 3x3 + BN + ReLU -> 1x1 16 -> 16 + BN -> + input): a thread owns
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         // broadcast from LDS) and the residual is the centre tap of the tile.  Stride 1, dilation 1 (host-checked).
         const float* pjw = (const float*)red;
         for (int p = tid; p < npo; p += 1024) {
-            const int oyl = (int)__umulhi((unsigned)p, invWo), ox = p - oyl * a.Wo;
+            const int oyl = fdiv(p, invWo), ox = p - oyl * TWo;
             const f32x4* e0 = ebuf + oyl * PWt + ox;
             f32x4 d[4];
 #pragma unroll
@@ -661,7 +675,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
                     if constexpr (sizeof(T) == 2) d[q][r] = (float)(f16)d[q][r];          // as the depthwise output would be stored
                 }
             }
-            T* yp = yb + (size_t)p * 16;
+            T* yp = yb + ((size_t)oyl * a.Wo + ox) * 16;
 #pragma unroll
             for (int qo = 0; qo < 4; ++qo) {
                 asm volatile("" ::: "memory");                       // keep the 272 weight floats in LDS, not hoisted into registers
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         const int q = it / npo_pad, p = it - q * npo_pad;            // q is wave-uniform
         const bool valid = p < npo;
         const int pp = valid ? p : 0;
-        const int oyl = (int)__umulhi((unsigned)pp, invWo), ox = pp - oyl * a.Wo;
+        const int oyl = fdiv(pp, invWo), ox = pp - oyl * TWo;
         const f32x4* eq = ebuf + q * a.npxs + (oyl * a.stride) * PWt + ox * a.stride;
         const float* wq = wd + q * 4;
         f32x4 acc = *(const f32x4*)(bd + q * 4);
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = act_f(acc[r], a.dact);
         const bool cok = c0 + q * 4 < cend;
-        if (valid && cok && !(a.dbg & 4)) st4f(yb + (size_t)p * a.C + c0 + q * 4, acc);
+        if (valid && cok && !(a.dbg & 4)) st4f(yb + ((size_t)oyl * a.Wo + ox) * a.C + c0 + q * 4, acc);
         if (a.hpart) {
             f32x4 s4;
 #pragma unroll
@@ -718,8 +732,8 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
         }
         __syncthreads();
         // fc1 partial: h[s] = sum_c W1[s][c0 + c] * psum[c]
-        const int nparts = gridDim.x * a.nband;
-        float* hp = a.hpart + ((size_t)n * nparts + slice * a.nband + band) * a.S;
+        const int nparts = gridDim.x * gridDim.y;
+        float* hp = a.hpart + ((size_t)n * nparts + (size_t)slice * gridDim.y + blockIdx.y) * a.S;
         if (tid < a.S) {
             float h = 0.f;
             if (c0 + a.cw <= a.C) {
@@ -736,7 +750,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     stamp(4);
 }
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s) {
-    dim3 grid((a.C + a.cw - 1) / a.cw, a.nband, N);
+    dim3 grid((a.C + a.cw - 1) / a.cw, a.nband * (a.ncol > 1 ? a.ncol : 1), N);
     const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
     const int kse = a.w ? a.KS : 0;                                  // 0..ED_KSMAX (host-checked)
     if (a.pj_w) { hipLaunchKernelGGL((mbconv_ed<T, 3, 0, true>), grid, dim3(1024), lds, s, a); return; }      // block 1

@@ -172,6 +172,31 @@ def test_fp32_shape_sweep_framewise_and_chunked(gc, H, W, ds, B):
         assert a.shape == b.shape and (a.cpu() - b).abs().max() < TOL32
 
 
+def test_column_tiled_depthwise_forced_on_a_small_frame(gc, monkeypatch):
+    """mbconv_ed in column tiles (the form wide frames need) forced on a small odd-sized frame: every tile edge, halo and
+    SE partial row against the oracle, all taps."""
+    monkeypatch.setenv("RVM_ED_CWT", "13")
+    w = gc.run("fp32", H=150, W=201, ds=0.8, T=2, B=2, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=122, W=218, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+
+
+def test_fp32_1080p_at_ratio_one():
+    """1920x1080 at downsample_ratio=1: the low-res map is the full frame, wider than any full-width LDS tile of the
+    depthwise kernel (column tiles) - the largest shape the reference runs on common inputs."""
+    from oracle import rvm_oracle as O
+    from robustvideomatting_amd import synthetic
+    m, p = _setup(torch.float32)
+    clip = synthetic.make_clip(1, 1080, 1920, seed=2)
+    with torch.no_grad():
+        got = m(clip[:, 0].cuda(), downsample_ratio=1.0)
+    want = O.forward(p, clip[:, 0], downsample_ratio=1.0)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and (a.cpu() - b).abs().max() < TOL32
+
+
 # ------------------------------------------------------------------ golden fixture (no oracle involved)
 @pytest.mark.parametrize("name", ["mobilenetv3_ds025", "mobilenetv3_ds1", "mobilenetv3_fast", "resnet50_ds025"])
 def test_against_committed_fixture(name):
