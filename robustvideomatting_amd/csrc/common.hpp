@@ -133,6 +133,7 @@ struct ConvArgs {
     void* hout2;                            // optional second copy of it (the caller's r_out)
     int state16;                            // hprev / hout are fp16 although the kernel computes in fp32
     int out2_mode;                          // IoMode of hout2 (IO_SAME: like hout)
+    float* part;                            // conv_kxk split-K: partial sums [nchunks][N][H][W][NT*16] (EPI_RELU only); null: one block runs all chunks
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 

@@ -227,8 +227,10 @@ struct rvm_ctx {
     std::map<std::string, Tap> taps;
     // plan-time tile selection by measurement (B*T > 1): launch key -> index into that launch's candidate list
     std::map<std::string, int> tuned;
-    struct Tunable { std::string key; int ncand, model; };
+    struct Tunable { std::string key; int ncand, model; bool always; };   // always: measured at plan time for single frames too
     std::vector<Tunable> tunable;                       // filled by build_plan: candidates and the model's choice
+    float* split_ws = nullptr;                          // conv_kxk split-K partial sums, shared by the launches that use it
+    size_t split_need = 0;
 
     // graph mode
     bool graph_mode = false;
@@ -380,7 +382,7 @@ size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC, SK) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC, SK);   // f32s == float
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
-                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0) {
+                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0, bool splittable = false) {
     auto W = c->P(wname);
     if (!W) { g_err = "missing parameter " + wname; return false; }
     int tot = 0, cin = 0;
@@ -395,7 +397,12 @@ bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout
     L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin; L.geo = geo; L.KD = geo == 3 ? 7 : 3;
     // one pass if the whole-channel halo patch fits comfortably, else channel chunks of <= 64 KiB
     L.CC = L.Cpad; L.nchunks = 1;
-    if (conv_lds(c, 1, geo, L.Cpad) > 150 * 1024) {
+    if (splittable && geo != 3 && L.Cpad >= 224) {
+        // long-K layers with a plain bias + ReLU epilogue (resnet50 bottleneck 3x3s, the decoder's cat convs): chunks of
+        // 56 channels (9 * 56 / 32 = 15.75 -> 16 K steps, no padding to speak of) that conv_kxk's split mode runs side by
+        // side on different CUs; 56 channels keep a 20-row tile's halo patch inside LDS
+        L.CC = 56; L.nchunks = cdiv(L.Cpad, 56);
+    } else if (conv_lds(c, 1, geo, L.Cpad) > 150 * 1024) {
         int cc = L.Cpad;
         while (cc > 8 && conv_lds(c, 1, geo, cc) > 64 * 1024) cc -= 8;
         L.CC = cc; L.nchunks = cdiv(L.Cpad, cc);
@@ -514,7 +521,7 @@ int finalize_impl(rvm_ctx* c) {
                 if (!pack_pw(c, p + ".conv1.weight", af, inpl, planes[l], ACT_RELU, R.c1)) return 1;
                 if (!bn_fold(c, p + ".bn2", planes[l], 1e-5f, af)) return 1;
                 const int geo = R.stride == 2 ? 1 : (d == 2 ? 2 : 0);
-                if (!pack_conv3(c, p + ".conv2.weight", af, planes[l], iota_map(planes[l], planes[l]), {planes[l]}, {planes[l]}, R.c2, geo)) return 1;
+                if (!pack_conv3(c, p + ".conv2.weight", af, planes[l], iota_map(planes[l], planes[l]), {planes[l]}, {planes[l]}, R.c2, geo, true)) return 1;
                 if (!bn_fold(c, p + ".bn3", planes[l] * 4, 1e-5f, af)) return 1;
                 if (!pack_pw(c, p + ".conv3.weight", af, planes[l], planes[l] * 4, ACT_RELU, R.c3)) return 1;
                 if (R.has_ds) {
@@ -541,7 +548,7 @@ int finalize_impl(rvm_ctx* c) {
         if (!bn_fold(c, p + ".conv.1", uout[i], 1e-5f, af)) return 1;
         // sources: up(a) | up(h) | f | s(NHWC4)   == reference cat[x, f, s] with x = cat[a, h]
         if (!pack_conv3(c, p + ".conv.0.weight", af, uout[i], iota_map(uout[i], rup(uout[i], 16)),
-                        {uin[i] / 2, uin[i] / 2, usk[i], 4}, {uin[i] / 2, uin[i] / 2, usk[i], 3}, c->up[i])) return 1;
+                        {uin[i] / 2, uin[i] / 2, usk[i], 4}, {uin[i] / 2, uin[i] / 2, usk[i], 3}, c->up[i], 0, true)) return 1;
         if (!pack_gru(c, p + ".gru", uout[i] / 2, c->gru[i + 1])) return 1;
     }
     if (!bn_fold(c, "decoder.decode0.conv.1", dec[3], 1e-5f, af)) return 1;
@@ -666,11 +673,12 @@ int build_plan(rvm_ctx* c) {
     c->taps.clear();
     c->tunable.clear();
     c->arena_used = 0;
-    auto tune_pick = [&](const std::string& name, int ncand, int model_choice) {
+    c->split_need = 0;
+    auto tune_pick = [&](const std::string& name, int ncand, int model_choice, bool always = false) {
         const std::string key = tune_key(name);
         bool seen = false;
         for (auto& t : c->tunable) seen |= t.key == key;
-        if (!seen) c->tunable.push_back({key, ncand, model_choice});
+        if (!seen) c->tunable.push_back({key, ncand, model_choice, always});
         auto it = c->tuned.find(key);
         return (it != c->tuned.end() && it->second >= 0 && it->second < ncand) ? it->second : model_choice;
     };
@@ -819,6 +827,45 @@ int build_plan(rvm_ctx* c) {
             if (nvalid == 0) return fail("conv: input patch does not fit LDS");
             const int pick = valid[tune_pick(name, nvalid, model)];
             MW = cand[pick][0]; NW = cand[pick][1];
+        } else if (L.nchunks > 1 && L.KD == 3 && epi == EPI_RELU && L.CC == 56) {
+            // Long-K layer packed in 56-channel chunks: conv_kxk's split mode (the chunks side by side on different CUs,
+            // partial sums added by a second pass) in several tile shapes, the one-block-per-tile chunk loop, and conv_sk.
+            // No latency model ranks these; the candidates are timed at plan time (always, a few ms per layer).
+            const int cS0 = geo == 1 ? 2 : 1, cD0 = geo == 2 ? 2 : 1;
+            struct Cand { int mw, nw, split; };               // split: 1 = chunks side by side (split-K), 0 = the one-block chunk loop
+            std::vector<Cand> cands;
+            if (geo != 1) { cands.push_back({5, 2, 1}); cands.push_back({5, 4, 1}); cands.push_back({5, 1, 1}); }
+            if (geo == 0) { cands.push_back({2, 2, 1}); cands.push_back({2, 1, 1}); }
+            cands.push_back({1, 2, 1});
+            cands.push_back({1, 2, 0});
+            bool sk_ok = true;
+            {
+                ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
+                fill(probe, none);
+                if (probe.nsrc < 1 || probe.nsrc > 2) sk_ok = false;
+                for (int k = 0; k < probe.nsrc && k < 2; ++k) if (probe.src[k].up || probe.src[k].C % 4) sk_ok = false;
+            }
+            if (sk_ok) cands.push_back({0, 1, 0});
+            std::vector<Cand> valid;
+            int model = 0;
+            for (const Cand& k : cands) {
+                if (k.mw && conv_lds_bytes<T>(k.mw, k.nw, 3, cS0, cD0, L.CC, k.nw == 4 ? 2 : 4) > 158 * 1024) continue;
+                if (k.nw > 1 && L.NT < k.nw) continue;
+                if (k.split > 1 && L.NT < k.nw * k.split) continue;
+                if (k.split && (int64_t)B * L.nchunks > 65535) continue;
+                valid.push_back(k);
+            }
+            if (valid.empty()) return fail("conv: input patch does not fit LDS");
+            // model choice (RVM_AUTOTUNE=0): split with the tallest tile that is not mostly empty
+            for (size_t k = 0; k < valid.size(); ++k)
+                if (valid[k].split && (valid[k].mw == 5 ? Ho >= 12 : true)) { model = (int)k; break; }
+            const Cand pick = valid[tune_pick(name, (int)valid.size(), model, true)];
+            MW = pick.mw; NW = pick.nw;
+            if (MW == 0) { a.cs = cS0; a.cd = cD0; }
+            if (pick.split) {
+                a.part = (float*)1;                                   // marker: the launch takes c->split_ws
+                c->split_need = std::max(c->split_need, (size_t)L.nchunks * B * Ho * Wo * L.NT * 16 * sizeof(float));
+            }
         } else {
             NW = 2;     // strided / dilated / 7x7 / chunked geometries are instantiated for MW=1, NW=2
             if (L.NT < 2 && epi != EPI_RELU) return fail("conv: unsupported tile shape");
@@ -838,6 +885,7 @@ int build_plan(rvm_ctx* c) {
             }
         }
         const int cS = (geo == 1 || geo == 3) ? 2 : 1, cD = geo == 2 ? 2 : 1;
+        if (NW == 4) SK0 = 2;                                   // four n-tiles per stage step: two steps fill a 16-byte piece per thread
         if (conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, SK0) > 160 * 1024) return fail("conv: input patch does not fit LDS");
         // weight stage depth: each stage costs one global round trip, so use the deepest that keeps the
         // block count per CU the grid needs (one block per CU when the grid is small)
@@ -846,7 +894,7 @@ int build_plan(rvm_ctx* c) {
         a.SK = SK0;
         if (MW == 0) { a.SK = 8; a.SKlog2 = 3; }                // conv_sk: no weight stages
         else {
-            const int blocks = a.tiles_x * cdiv(Ho, 4 * MW) * cdiv(L.NT, NW) * B;
+            const int blocks = a.tiles_x * cdiv(Ho, 4 * MW) * cdiv(L.NT, NW) * B * (a.part ? L.nchunks : 1);
             const size_t budget = blocks <= 256 ? 150 * 1024 : (blocks <= 512 ? 78 * 1024 : 52 * 1024);
             const char* e = getenv("RVM_CONV_SK");
             const int skmax = e ? atoi(e) : 8;
@@ -858,7 +906,11 @@ int build_plan(rvm_ctx* c) {
                         conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, a.SK));
         }
         const double KK = (double)L.KD * L.KD;
-        auto fn = [=](hipStream_t st, const FrameIO& io) { ConvArgs b = a; fill(b, io); launch_conv3_m<T>(b, B, MW, NW, geo, st, split); };
+        auto fn = [=](hipStream_t st, const FrameIO& io) {
+            ConvArgs b = a; fill(b, io);
+            if (a.part) b.part = c->split_ws;
+            launch_conv3_m<T>(b, B, MW, NW, geo, st, split);
+        };
         if (keep) { *keep = fn; return 0; }
         // algorithmic bytes: every source at the resolution and element size it is READ at (a x2-upsampled source is
         // read at half size, an fp16 state as 2 bytes), the epilogue's own operands, the output(s), the weights once
@@ -1218,6 +1270,7 @@ int build_plan(rvm_ctx* c) {
                 }, 2);
         }
     }
+    c->split_ws = c->split_need ? (float*)c->arena_alloc(c->split_need) : nullptr;
     return plan_bad ? 1 : 0;
 }
 
@@ -1225,7 +1278,12 @@ int build_plan(rvm_ctx* c) {
 // latency model build_plan uses for one frame (rounds of blocks x work per block) no longer ranks the
 // tiles; here every candidate of every GEMM / conv launch is timed on the device (hipEvents, a few
 // repetitions on dummy states) and the fastest kept.  Runs inside rvm_plan, never on the frame path.
-int autotune(rvm_ctx* c) {
+int autotune(rvm_ctx* c, bool only_always) {
+    if (only_always) {
+        bool any = false;
+        for (const auto& t : c->tunable) any |= t.always && t.ncand > 1;
+        if (!any) return 0;
+    }
     auto rebuild = [&]() { return c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c); };
     const size_t ses = c->dtype == RVM_DTYPE_F32 ? 4 : 2;
     const int ch[4] = {c->dec[2] / 2, c->dec[1] / 2, c->dec[0] / 2, c->feat[3] / 2};
@@ -1253,7 +1311,7 @@ int autotune(rvm_ctx* c) {
     const auto tunable = c->tunable;                      // build_plan refills the list
     const bool verbose = getenv("RVM_VERBOSE") != nullptr;
     for (const auto& t : tunable) {
-        if (t.ncand < 2) continue;
+        if (t.ncand < 2 || (only_always && !t.always)) continue;
         // the launches a key stands for: the one of that name, or - for "mbN.ed", the band height of the fused
         // expand -> depthwise kernel - that kernel together with the separate expand GEMM some heights imply
         const bool ed = t.key.size() > 3 && t.key.compare(t.key.size() - 3, 3, ".ed") == 0;
@@ -1322,7 +1380,8 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     {
         const char* e = getenv("RVM_AUTOTUNE");           // "0": never, "1": also for a single frame
         const bool tune = e ? atoi(e) != 0 && ((int64_t)B * T > 1 || atoi(e) == 1) : (int64_t)B * T > 1;
-        if (tune && (rc = autotune(c))) return rc;
+        const bool off = e && atoi(e) == 0;               // the reproducible mode: model choices only
+        if (!off && (rc = autotune(c, !tune))) return rc;
     }
     c->planned = true;
     return 0;

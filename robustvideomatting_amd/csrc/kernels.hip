@@ -1032,8 +1032,8 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
 // The concatenated input channels are processed in chunks of a.CC channels (one chunk for the
 // mobilenetv3 decoder; several for the resnet50 layers whose halo patch would not fit LDS);
 // K index inside a chunk = tap * chunk_channels + channel.
-template <typename T, int MW, int NW, int KD, int S, int D>
-__global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false>
+__global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs a) {   // 20-row tiles: one block per CU (LDS), registers to spare
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* patch = (T*)smem;
@@ -1050,7 +1050,13 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     T* wbuf = patch + (size_t)PH * PW * CSL;                // [2][NW][SK][512]
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const int y0 = ty * TH, x0 = tx * 16, n = blockIdx.z;
+    // split mode (a.part != null): blockIdx.z = sample x channel chunk; the block runs ONE chunk of the K loop and leaves
+    // its raw partial sums in a.part[chunk] - the chunks of a long-K layer run side by side on different CUs instead of
+    // one after the other in few blocks; conv_split_reduce adds them in chunk order and applies the epilogue
+    constexpr bool splitk = SPLIT;                          // compile-time: the one-block-per-tile form compiles as it always did
+    const int n = splitk ? (int)blockIdx.z / a.nchunks : (int)blockIdx.z;
+    const int chunk0 = splitk ? (int)blockIdx.z - n * a.nchunks : 0;
+    const int y0 = ty * TH, x0 = tx * 16;
     const int H = a.H, W = a.W;                             // output size
     const int gy0 = y0 * S - G::PAD, gx0 = x0 * S - G::PAD; // patch origin in input coordinates
 
@@ -1092,7 +1098,8 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
         for (int j = 0; j < NPMAX; ++j)
             if (j < NP) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + CONV_NT * j) * 16) = wr[j];
     };
-    wload(0);                                               // in flight while the patch is staged
+    const int KSfull = ((KK * a.CC + 31) / 32 + 7) / 8 * 8;   // K steps of a full channel chunk (several chunks: padded to 8)
+    wload(chunk0 * KSfull);                                 // in flight while the patch is staged
 
     f32x4 acc[MW][NW];
 #pragma unroll
@@ -1100,8 +1107,9 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
-    int gs = 0, buf = 0;                                     // global K step at the start of the stage
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    int gs = chunk0 * KSfull, buf = 0;                       // global K step at the start of the stage
+    const int chunk_end = splitk ? chunk0 + 1 : a.nchunks;
+    for (int chunk = chunk0; chunk < chunk_end; ++chunk) {
         const int c_lo = chunk * a.CC;
         const int CCc = min(a.CC, a.Cpad - c_lo);
         const int KSc = a.nchunks > 1 ? ((KK * CCc + 31) / 32 + 7) / 8 * 8 : a.KS;
@@ -1121,8 +1129,9 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
                         if (hf) stage_source<T, true, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tl, nthr);
                         else stage_source<T, true, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, H, W, tl, nthr);
                     } else {
-                        if (hf) stage_source<T, false, true, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
-                        else stage_source<T, false, false, PH, PW>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
+                        constexpr int UND = (SPLIT && MW >= 5) ? 8 : 4;      // loads in flight per thread (the big tiles have registers to spare)
+                        if (hf) stage_source<T, false, true, PH, PW, UND>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
+                        else stage_source<T, false, false, PH, PW, UND>(patch, a.src[s], q_lo, q_cnt, dst_c, CSL, n, gy0, gx0, a.Hi, a.Wi, tl, nthr);
                     }
                 }
                 coff += C;
@@ -1133,20 +1142,20 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
                     for (int cch = used; cch < CCc; cch += 4) stp4(patch + pp * CSL, cch, f32x4{0, 0, 0, 0});
             }
         }
-        if (chunk == 0) wstore(0);
+        if (chunk == chunk0) wstore(0);
         // Every load so far has landed (the LDS stores above used them) except, as far as the compiler can tell, the
         // padding loads of partly filled staging rounds; say so, or it guards the first register reuse in the K loop
         // with a vmcnt(0) that also waits for the weight stage in flight, on every K step.
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
         __syncthreads();
-        if (chunk == 0) stamp(1);
+        if (chunk == chunk0) stamp(1);
 
         // ---- implicit GEMM over this chunk, SK steps per weight stage ----
         const int NQ8 = CCc >> 3;
         int tap = 0, c8 = g + 4 * kgrp;                          // K group 1 starts one step in
         while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
         for (int ks0 = 0; ks0 < ((a.dbg & 2) ? 0 : KSc); ks0 += SK) {
-            const bool more = gs + SK < a.KS && !(a.dbg & 8);
+            const bool more = (splitk ? ks0 + SK < KSc : gs + SK < a.KS) && !(a.dbg & 8);
             if (more) wload(gs + SK);
             const T* wst = wbuf + (size_t)buf * WSTAGE;
             for (int p = kgrp; p < SK; p += 2) {
@@ -1194,6 +1203,21 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     // ---- epilogue ----
     stamp(2);
     const int gx = x0 + l15;
+    if constexpr (splitk) {                                  // raw partial sums [chunk][sample][H][W][NT * 16]
+        const int NC = a.NT * 16;
+        float* part = a.part + (size_t)chunk0 * (gridDim.z / a.nchunks) * H * W * NC;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int gy = y0 + wave + 4 * mi;
+            if (gy >= H || gx >= W) continue;
+            const size_t pix = ((size_t)n * H + gy) * W + gx;
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni)
+                if (nv[ni]) *(f32x4*)(part + pix * NC + (nt0 + ni) * 16 + g * 4) = acc[mi][ni];
+        }
+        stamp(3);
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int gy = y0 + wave + 4 * mi;
@@ -1247,6 +1271,29 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_kxk(ConvArgs a) {
     stamp(3);
 }
 
+// Second pass of a split-K conv_kxk launch: y = relu(bias + sum of the partial sums, in (chunk, K group) order).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_split_reduce(ConvArgs a, long quads) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const int CQ = a.Cout >> 2, NC = a.NT * 16;
+    const long pix = i / CQ;
+    const int ch = (int)(i - pix * CQ) * 4;
+    const size_t per = (size_t)(quads / CQ) * NC;            // elements of one chunk's partial tensor
+    const float* p = a.part + (size_t)pix * NC + ch;
+    f32x4 v[4], s = *(const f32x4*)(a.bias + ch);
+    const int nparts = a.nchunks;
+    for (int c0 = 0; c0 < nparts; c0 += 4) {                 // four partial sums in flight, added in chunk order
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *(const f32x4*)(p + (size_t)min(c0 + k, nparts - 1) * per);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (c0 + k < nparts) s += v[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = fmaxf(s[r], 0.f);
+    st4f((T*)a.y + (size_t)pix * a.ys + ch, s);
+}
+
 // Waves of a conv_kxk block per source, in proportion to the loads the source's part of the halo patch takes
 // (the sources lie along a [0, 8) wave axis; a wave on a boundary stages both neighbours, one after the other).
 static void conv_assign_waves(ConvArgs& a, int PH, int PW) {
@@ -1271,14 +1318,23 @@ static void conv_assign_waves(ConvArgs& a, int PH, int PW) {
         at += cost[k];
     }
 }
-template <typename T, int MW, int NW, int KD, int S, int D>
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLITOK = false>
 static void launch_conv_t(const ConvArgs& a_, int N, hipStream_t s) {
     ConvArgs a = a_;
     conv_assign_waves(a, ConvGeo<MW, KD, S, D>::PH, ConvGeo<MW, KD, S, D>::PW);
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
-    dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, N);
-    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(CONV_NT), conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.SK), s, a);
+    dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, a.part ? N * a.nchunks : N);
+    const size_t lds = conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.SK);
+    if constexpr (SPLITOK) {
+        if (a.part) {
+            hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D, true>), grid, dim3(CONV_NT), lds, s, a);
+            const long quads = (long)N * a.H * a.W * (a.Cout / 4);
+            hipLaunchKernelGGL((conv_split_reduce<T>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D>), grid, dim3(CONV_NT), lds, s, a);
 }
 // geo: 0 = 3x3 s1 d1, 1 = 3x3 s2 d1, 2 = 3x3 s1 d2, 3 = 7x7 s2 d1 (geometries 1..3 exist for MW=1, NW=2 only)
 // ------------------------------------------------------------------------------------------
@@ -1515,13 +1571,22 @@ template <typename T, int NW> static void launch_conv_sk(const ConvArgs& a, int 
 }
 template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW, int geo, hipStream_t s) {
     if (MW == 0) { if (NW == 2) launch_conv_sk<T, 2>(a, N, s); else launch_conv_sk<T, 1>(a, N, s); return; }   // small-map form
-    if (geo == 1) { launch_conv_t<T, 1, 2, 3, 2, 1>(a, N, s); return; }
-    if (geo == 2) { launch_conv_t<T, 1, 2, 3, 1, 2>(a, N, s); return; }
+    if (geo == 1) { launch_conv_t<T, 1, 2, 3, 2, 1, true>(a, N, s); return; }
+    if (geo == 2) {
+        if (MW == 5 && NW == 4) launch_conv_t<T, 5, 4, 3, 1, 2, true>(a, N, s);
+        else if (MW == 5 && NW == 1) launch_conv_t<T, 5, 1, 3, 1, 2, true>(a, N, s);
+        else if (MW == 5) launch_conv_t<T, 5, 2, 3, 1, 2, true>(a, N, s);
+        else launch_conv_t<T, 1, 2, 3, 1, 2, true>(a, N, s);
+        return;
+    }
     if (geo == 3) { launch_conv_t<T, 1, 2, 7, 2, 1>(a, N, s); return; }
-    if (MW == 4 && NW == 1) launch_conv_t<T, 4, 1, 3, 1, 1>(a, N, s);
-    else if (MW == 2 && NW == 2) launch_conv_t<T, 2, 2, 3, 1, 1>(a, N, s);
-    else if (MW == 2 && NW == 1) launch_conv_t<T, 2, 1, 3, 1, 1>(a, N, s);
-    else if (MW == 1 && NW == 2) launch_conv_t<T, 1, 2, 3, 1, 1>(a, N, s);
+    if (MW == 5 && NW == 4) launch_conv_t<T, 5, 4, 3, 1, 1, true>(a, N, s);
+    else if (MW == 5 && NW == 1) launch_conv_t<T, 5, 1, 3, 1, 1, true>(a, N, s);
+    else if (MW == 5 && NW == 2) launch_conv_t<T, 5, 2, 3, 1, 1, true>(a, N, s);
+    else if (MW == 4 && NW == 1) launch_conv_t<T, 4, 1, 3, 1, 1>(a, N, s);
+    else if (MW == 2 && NW == 2) launch_conv_t<T, 2, 2, 3, 1, 1, true>(a, N, s);
+    else if (MW == 2 && NW == 1) launch_conv_t<T, 2, 1, 3, 1, 1, true>(a, N, s);
+    else if (MW == 1 && NW == 2) launch_conv_t<T, 1, 2, 3, 1, 1, true>(a, N, s);
     else launch_conv_t<T, 1, 1, 3, 1, 1>(a, N, s);
 }
 template void launch_conv3<f16>(const ConvArgs&, int, int, int, int, hipStream_t);
@@ -2520,13 +2585,18 @@ template void launch_maxpool<f16>(const MaxPoolArgs&, int, hipStream_t);
 template void launch_maxpool<float>(const MaxPoolArgs&, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int MW, int NW, int KD, int S, int D> static void conv_attr() {
-    (void)hipFuncSetAttribute((const void*)conv_kxk<T, MW, NW, KD, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false> static void conv_attr() {
+    (void)hipFuncSetAttribute((const void*)conv_kxk<T, MW, NW, KD, S, D, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename T> static void conv_attr_all() {
     conv_attr<T, 4, 1, 3, 1, 1>(); conv_attr<T, 2, 2, 3, 1, 1>(); conv_attr<T, 2, 1, 3, 1, 1>();
     conv_attr<T, 1, 2, 3, 1, 1>(); conv_attr<T, 1, 1, 3, 1, 1>();
     conv_attr<T, 1, 2, 3, 2, 1>(); conv_attr<T, 1, 2, 3, 1, 2>(); conv_attr<T, 1, 2, 7, 2, 1>();
+    conv_attr<T, 5, 1, 3, 1, 1>(); conv_attr<T, 5, 2, 3, 1, 1>(); conv_attr<T, 5, 1, 3, 1, 2>(); conv_attr<T, 5, 2, 3, 1, 2>();
+    conv_attr<T, 5, 1, 3, 1, 1, true>(); conv_attr<T, 5, 2, 3, 1, 1, true>(); conv_attr<T, 5, 1, 3, 1, 2, true>(); conv_attr<T, 5, 2, 3, 1, 2, true>();
+    conv_attr<T, 5, 4, 3, 1, 1>(); conv_attr<T, 5, 4, 3, 1, 2>(); conv_attr<T, 5, 4, 3, 1, 1, true>(); conv_attr<T, 5, 4, 3, 1, 2, true>();
+    conv_attr<T, 2, 2, 3, 1, 1, true>(); conv_attr<T, 2, 1, 3, 1, 1, true>(); conv_attr<T, 1, 2, 3, 1, 1, true>();
+    conv_attr<T, 1, 2, 3, 2, 1, true>(); conv_attr<T, 1, 2, 3, 1, 2, true>();
 }
 void kernels_init() {
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();

@@ -44,15 +44,10 @@ def main():
     n = len(names)
     (total, total1), st, st1 = native.debug_stamps()
     assert total > 0, "library was not built with RVM_STAMPS"
-    assert total % n == 0, (total, n)
     nfr = min(512 // n - 1, a.frames - 2)
     single = [i for i in range(n)]      # launches whose grid has one block never write table 1
     acc = [[0.0, [0.0] * 14, [0.0] * 14, 0.0] for _ in range(n)]
     # table 1 rows are counted separately: only launches with > 1 block appear, in launch order
-    multi = None
-    if total1 % (total // n) == 0:
-        per_frame1 = total1 // (total // n)
-        multi = per_frame1
     for f in range(nfr):
         first = total - (f + 1) * n            # launch counter value of this frame's launch 0
         for i in range(n):
@@ -66,7 +61,7 @@ def main():
     # match table-1 rows to launches by start time: the last block of launch i starts after block 0 of
     # launch i and before block 0 of launch i+1
     rows1 = sorted((r for r in st1 if r[0]), key=lambda r: r[0])
-    starts = sorted(((st[(total - 1 - j) % 512][0], (total - 1 - j) % n) for j in range(min(total, 512))), key=lambda t: t[0])
+    starts = sorted(((st[(total - 1 - j) % 512][0], n - 1 - j % n) for j in range(min(total, 512))), key=lambda t: t[0])
     import bisect
     keys = [t[0] for t in starts]
     cnt = [0] * n
