@@ -77,6 +77,17 @@ int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
 int rvm_forward(rvm_ctx* ctx, const void* src, const void* const r_in[4], void* fgr, void* pha,
                 void* const r_out[4], int seg_pass, void* hip_stream);
 
+/* rvm_forward with the driver's output step fused into the refiner's full-resolution pass: instead of
+ * fgr / pha the last kernel writes the composed uint8 frames the reference's writers receive - convert_video's
+ * composition (inference.py:116,137-141) followed by `frames.mul(255).byte()` and the NCHW->NHWC permute
+ * (inference_utils.py:44) - `out` uint8 [B,H,W,C] (C = 4 for RVM_COMPOSE_RGBA, else 3; [T*B,...] time-major after
+ * rvm_plan_seq).  The bytes equal rvm_compose_u8 applied to what rvm_forward would have written (fgr / pha are rounded
+ * to the tensor dtype first, every op of the composition rounds like the torch ops).  Half the output bytes of the
+ * refiner pass and no second pass over fgr / pha.  Needs a refining plan (downsample_ratio != 1); modes and `bgr` as for
+ * rvm_compose_u8 below. */
+int rvm_forward_u8(rvm_ctx* ctx, const void* src, const void* const r_in[4], uint8_t* out, void* const r_out[4],
+                   int mode, const float bgr[3], void* hip_stream);
+
 /* Output step of the reference driver, on the device: convert_video's composition
  * (inference.py:116,137-141: com = fgr*pha + bgr*(1-pha) with bgr = (120,255,155)/255 for video output;
  * cat[fgr*(pha>0), pha] for png_sequence output) fused with the writers' `frames.mul(255).byte()` and

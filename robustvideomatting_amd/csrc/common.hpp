@@ -172,6 +172,8 @@ struct DgfApplyArgs {
     const void* src; const float* ab; void* fgr; void* pha;
     int H, W, h, w; float scale_y, scale_x;
     int ncols;                              // low-res columns one 2048-px row segment can touch (LDS tile)
+    // fused driver output (rvm_forward_u8): composed uint8 [N][H][W][C] instead of fgr / pha; null: fgr / pha
+    unsigned char* u8; int u8mode; float bgr[3];
 };
 struct ProjOutArgs { const void* hid; const void* src; const DgfWeights* wt; void* fgr; void* pha; int H, W, seg; };
 

@@ -183,6 +183,7 @@ struct Tap { const void* p; int B, H, W, C, Cs; bool is_float; };
 
 struct FrameIO {
     const void* src; const void* r_in[4]; void* fgr; void* pha; void* r_out[4]; int64_t seg;
+    unsigned char* u8; int64_t u8mode; float bgr[4];       // rvm_forward_u8: composed uint8 frames instead of fgr / pha
     bool operator==(const FrameIO& o) const { return memcmp(this, &o, sizeof(FrameIO)) == 0; }
 };
 
@@ -1236,7 +1237,7 @@ int build_plan(rvm_ctx* c) {
             lo.mlp = wb + c->dgf_mlp;
             lo.hin = hidA; lo.cw = wb + c->out1.w; lo.cbias = (const float*)(wb + c->out1.bias); lo.csplit = split ? 1 : 0;
         }
-        DgfApplyArgs ap; ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
+        DgfApplyArgs ap; memset(&ap, 0, sizeof ap); ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
         ap.ncols = std::min(c->w, (int)std::ceil(2048.0 * ap.scale_x) + 3);
         ProjOutArgs po; po.hid = hid; po.wt = dw; po.H = c->h; po.W = c->w;
@@ -1259,6 +1260,7 @@ int build_plan(rvm_ctx* c) {
                         launch_proj_out<T>(q, B, io16, st);
                     } else {
                         DgfApplyArgs q = ap; q.src = io.src; q.fgr = io.fgr; q.pha = io.pha;
+                        q.u8 = io.u8; q.u8mode = (int)io.u8mode; q.bgr[0] = io.bgr[0]; q.bgr[1] = io.bgr[1]; q.bgr[2] = io.bgr[2];
                         launch_dgf_apply<T>(q, B, io16, st);
                     }
                 }, 2);
@@ -1493,12 +1495,32 @@ int rvm_set_graph_mode(rvm_ctx* c, int enabled) {
     return 0;
 }
 
+static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void* const r_out[4], void* hip_stream);
+
 int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fgr, void* pha,
                 void* const r_out[4], int seg_pass, void* hip_stream) {
     if (!c || !c->planned) return fail("rvm_forward: no plan (call rvm_plan)");
     if (!src || !pha || !r_out || (!seg_pass && !fgr)) return fail("rvm_forward: null buffer");
     FrameIO io; memset(&io, 0, sizeof io);
     io.src = src; io.fgr = fgr; io.pha = pha; io.seg = seg_pass ? 1 : 0;
+    return forward_impl(c, io, r_in, r_out, hip_stream);
+}
+
+int rvm_forward_u8(rvm_ctx* c, const void* src, const void* const r_in[4], uint8_t* out, void* const r_out[4],
+                   int mode, const float bgr[3], void* hip_stream) {
+    if (!c || !c->planned) return fail("rvm_forward_u8: no plan (call rvm_plan)");
+    if (!src || !out || !r_out) return fail("rvm_forward_u8: null buffer");
+    if (mode < 0 || mode > 3) return fail("rvm_forward_u8: bad mode");
+    if (mode == RVM_COMPOSE_GREEN && !bgr) return fail("rvm_forward_u8: background colour missing");
+    if (c->ds == 1.0) return fail("rvm_forward_u8: the fused uint8 output belongs to the refiner's full-resolution pass; with "
+                                  "downsample_ratio == 1 use rvm_forward + rvm_compose_u8");
+    FrameIO io; memset(&io, 0, sizeof io);
+    io.src = src; io.u8 = out; io.u8mode = mode;
+    for (int k = 0; k < 3; ++k) io.bgr[k] = bgr ? bgr[k] : 0.f;
+    return forward_impl(c, io, r_in, r_out, hip_stream);
+}
+
+static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void* const r_out[4], void* hip_stream) {
     for (int i = 0; i < 4; ++i) {
         io.r_in[i] = r_in ? r_in[i] : nullptr;
         io.r_out[i] = r_out[i];
@@ -1521,6 +1543,7 @@ int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fg
     while (hi > lo && c->launches[hi - 1].edge == 2) --hi;
     for (size_t i = 0; i < lo; ++i) c->launches[i].fn(st, io);
     FrameIO key = io; key.src = nullptr; key.fgr = nullptr; key.pha = nullptr;
+    key.u8 = nullptr; key.u8mode = 0; memset(key.bgr, 0, sizeof key.bgr);          // only the last (eager) launch sees these
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
         if (g.key == key) { exec = g.exec; break; }

@@ -2209,6 +2209,36 @@ template <> struct Out8<float> {
     __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = f32x4{r[0], r[1], r[2], r[3]}; *(f32x4*)(p + 4) = f32x4{r[4], r[5], r[6], r[7]}; }
     __device__ __forceinline__ float get(int j) const { return r[j]; }
 };
+// Output step of the reference driver (inference.py:116,137-141; inference_utils.py:44), one pixel: every tensor op of the
+// reference rounds to the tensor dtype, so the arithmetic is written in that type (TIO) op by op and the bytes come out
+// identical.  Used by compose_u8 (its own pass over fgr / pha) and by dgf_apply's fused uint8 output.
+template <typename TIO> __device__ __forceinline__ unsigned char to_byte(TIO v) {
+    const TIO m = v * (TIO)255.0f;                                   // .mul(255) in the tensor dtype
+    return (unsigned char)(int)(float)m;                            // .byte(): truncation (values are in [0, 255])
+}
+template <typename TIO>
+__device__ __forceinline__ unsigned compose_px(int mode, TIO f0, TIO f1, TIO f2, TIO al, const float* bgr) {
+    if (mode == COMPOSE_ALPHA) { const unsigned b = to_byte<TIO>(al); return b | (b << 8) | (b << 16); }
+    const TIO one = (TIO)1.0f, zero = (TIO)0.0f;
+    TIO f[3] = {f0, f1, f2};
+    unsigned out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        TIO v = f[c];
+        if (mode == COMPOSE_GREEN) {
+#pragma clang fp contract(off)                                       // no fma: the reference rounds after every op
+            const TIO t1 = v * al;                                   // each op rounds to TIO like the torch ops do
+            const TIO t2 = one - al;
+            const TIO t3 = (TIO)bgr[c] * t2;
+            v = t1 + t3;
+        } else if (mode == COMPOSE_RGBA) {
+            v = v * (al > zero ? one : zero);
+        }
+        out |= (unsigned)to_byte<TIO>(v) << (8 * c);
+    }
+    if (mode == COMPOSE_RGBA) out |= (unsigned)to_byte<TIO>(al) << 24;
+    return out;
+}
 // Block = one segment of 2048 consecutive x of one row (256 threads x 8 px).  The A|b rows are first
 // interpolated vertically for the low-res columns the segment touches and parked in LDS
 // ([column][8] fp32), then every thread interpolates horizontally out of LDS, branch-free, and packs
@@ -2300,6 +2330,32 @@ __global__ __launch_bounds__(256, 6) void dgf_apply(DgfApplyArgs a) {      // <=
         for (int c = 0; c < 3; ++c) of[c].set(jp, o[0][c], o[1][c]);
         op.set(jp, o[0][3], o[1][3]);
     }
+    if (a.u8) {
+        // fused driver output: composed uint8 NHWC instead of fgr / pha (the values are first rounded to TIO exactly as
+        // the fgr / pha tensors would hold them)
+        unsigned px[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) px[j] = compose_px<TIO>(a.u8mode, of[0].get(j), of[1].get(j), of[2].get(j), op.get(j), a.bgr);
+        const size_t p0 = (size_t)n * plane + (size_t)y * a.W + x0;
+        if (a.u8mode == COMPOSE_RGBA) {
+            unsigned* o = (unsigned*)(a.u8 + p0 * 4);
+            if (full) { *(u32x4*)o = u32x4{px[0], px[1], px[2], px[3]}; *(u32x4*)(o + 4) = u32x4{px[4], px[5], px[6], px[7]}; }
+            else for (int j = 0; j < 8; ++j) if (x0 + j < a.W) o[j] = px[j];
+        } else if (full) {
+            // 8 px x 3 bytes = 24 bytes at an 8-byte aligned address (x0 % 8 == 0, W % 8 == 0)
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2* o = (u32x2*)(a.u8 + p0 * 3);
+            const unsigned w0 = (px[0] & 0xFFFFFF) | (px[1] << 24), w1 = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
+            const unsigned w2 = ((px[2] >> 16) & 0xFF) | (px[3] << 8), w3 = (px[4] & 0xFFFFFF) | (px[5] << 24);
+            const unsigned w4 = ((px[5] >> 8) & 0xFFFF) | (px[6] << 16), w5 = ((px[6] >> 16) & 0xFF) | (px[7] << 8);
+            o[0] = u32x2{w0, w1}; o[1] = u32x2{w2, w3}; o[2] = u32x2{w4, w5};
+        } else {
+            unsigned char* o = a.u8 + p0 * 3;
+            for (int j = 0; j < 8; ++j)
+                if (x0 + j < a.W) { o[3 * j] = px[j] & 0xFF; o[3 * j + 1] = (px[j] >> 8) & 0xFF; o[3 * j + 2] = (px[j] >> 16) & 0xFF; }
+        }
+        return;
+    }
     TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
     TIO* pp = (TIO*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
     if (full) {
@@ -2383,10 +2439,6 @@ template void launch_proj_out<float>(const ProjOutArgs&, int, int, hipStream_t);
 //   ALPHA      pha repeated to 3 channels                  C = 3   (VideoWriter grayscale -> RGB)
 //   FOREGROUND fgr                                         C = 3
 // ------------------------------------------------------------------------------------------
-template <typename TIO> __device__ __forceinline__ unsigned char to_byte(TIO v) {
-    const TIO m = v * (TIO)255.0f;                                   // .mul(255) in the tensor dtype
-    return (unsigned char)(int)(float)m;                            // .byte(): truncation (values are in [0, 255])
-}
 template <typename TIO>
 __global__ __launch_bounds__(256) void compose_u8(ComposeArgs a) {
     [[maybe_unused]] Stamper stamp;
@@ -2394,31 +2446,17 @@ __global__ __launch_bounds__(256) void compose_u8(ComposeArgs a) {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y;
     if (p >= plane) return;
-    const TIO* f = (const TIO*)a.fgr + (size_t)n * 3 * plane + p;
     const TIO al = ((const TIO*)a.pha)[(size_t)n * plane + p];
     const int C = a.mode == COMPOSE_RGBA ? 4 : 3;
     unsigned char* o = a.out + ((size_t)n * plane + p) * C;
-    if (a.mode == COMPOSE_ALPHA) {
-        const unsigned char b = to_byte<TIO>(al);
-        o[0] = b; o[1] = b; o[2] = b;
-        return;
+    TIO f0 = (TIO)0.f, f1 = (TIO)0.f, f2 = (TIO)0.f;
+    if (a.mode != COMPOSE_ALPHA) {
+        const TIO* f = (const TIO*)a.fgr + (size_t)n * 3 * plane + p;
+        f0 = f[0]; f1 = f[plane]; f2 = f[2 * plane];
     }
-    const TIO one = (TIO)1.0f, zero = (TIO)0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        TIO v = f[c * plane];
-        if (a.mode == COMPOSE_GREEN) {
-#pragma clang fp contract(off)                                       // no fma: the reference rounds after every op
-            const TIO t1 = v * al;                                   // each op rounds to TIO like the torch ops do
-            const TIO t2 = one - al;
-            const TIO t3 = (TIO)a.bgr[c] * t2;
-            v = t1 + t3;
-        } else if (a.mode == COMPOSE_RGBA) {
-            v = v * (al > zero ? one : zero);
-        }
-        o[c] = to_byte<TIO>(v);
-    }
-    if (a.mode == COMPOSE_RGBA) o[3] = to_byte<TIO>(al);
+    const unsigned px = compose_px<TIO>(a.mode, f0, f1, f2, al, a.bgr);
+    o[0] = px & 0xFF; o[1] = (px >> 8) & 0xFF; o[2] = (px >> 16) & 0xFF;
+    if (C == 4) o[3] = px >> 24;
 }
 void launch_compose(const ComposeArgs& a, int N, int io, hipStream_t s) {
     const dim3 grid((unsigned)(((size_t)a.H * a.W + 255) / 256), N);

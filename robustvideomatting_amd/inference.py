@@ -183,6 +183,22 @@ def convert_video(model,
                 if downsample_ratio is None:
                     downsample_ratio = auto_downsample_ratio(*chunk.shape[2:])
                 src = chunk.to(device, dtype, non_blocking=True).unsqueeze(0)                          # [1,T,3,H,W]
+                # One output only and a refining ratio: the composition / byte conversion rides on the refiner's
+                # full-resolution kernel (rvm_forward_u8) - half the bytes written, no second pass over fgr / pha.
+                wanted = [w for w in (writer_com, writer_pha, writer_fgr) if w is not None]
+                if len(wanted) == 1 and downsample_ratio != 1 and hasattr(model, "forward_u8"):
+                    if writer_com is not None:
+                        mode = native.COMPOSE_GREEN if output_type == 'video' else native.COMPOSE_RGBA
+                    else:
+                        mode = native.COMPOSE_ALPHA if writer_pha is not None else native.COMPOSE_FOREGROUND
+                    frames, *rec = model.forward_u8(src, *rec, downsample_ratio=downsample_ratio, mode=mode, bgr=bgr)
+                    frames = frames[0]
+                    if writer_pha is not None and output_type != 'video':
+                        frames = frames[..., :1]                        # to_pil_image of a 1-channel tensor: mode L
+                    wanted[0].write(frames.cpu().numpy())
+                    if progress:
+                        print("\r%d / %d frames" % (min(start + seq_chunk, n), n), end="", flush=True)
+                    continue
                 # the second src is the placeholder for the trimap (inference.py:128-129)
                 fgr, pha, *rec = model(src, src, *rec, downsample_ratio)
                 fgr, pha = fgr[0].contiguous(), pha[0].contiguous()

@@ -222,7 +222,16 @@ class MattingNetwork(nn.Module):
         """Explicit upstream-RVM signature (README.md:184 of the reference)."""
         return self._run(src, [r1, r2, r3, r4], float(downsample_ratio), bool(segmentation_pass))
 
-    def _run(self, src, rec, ds, seg):
+    def forward_u8(self, src, r1=None, r2=None, r3=None, r4=None, downsample_ratio: float = 1,
+                   mode: int = native.COMPOSE_GREEN, bgr=None):
+        """forward + the driver's output step in one pass (rvm_forward_u8): returns ``[frames_u8, r1, r2, r3, r4]`` with
+        ``frames_u8`` uint8 ``[B,H,W,C]`` (``[B,T,H,W,C]`` for a 5-D src) - what the reference's writers get after
+        convert_video's composition, ``.mul(255).byte()`` and the NHWC permute (inference.py:137-141, inference_utils.py:44).
+        ``mode``: native.COMPOSE_GREEN (needs ``bgr``), COMPOSE_RGBA, COMPOSE_ALPHA, COMPOSE_FOREGROUND.  Needs
+        ``downsample_ratio != 1`` (the composition rides on the refiner's full-resolution kernel)."""
+        return self._run(src, [r1, r2, r3, r4], float(downsample_ratio), False, u8=(int(mode), bgr))
+
+    def _run(self, src, rec, ds, seg, u8=None):
         if not isinstance(src, Tensor) or src.ndim not in (4, 5) or src.shape[-3] != 3:
             raise RuntimeError("src must be [B,3,H,W] or [B,T,3,H,W]")
         if not src.is_cuda:
@@ -264,6 +273,8 @@ class MattingNetwork(nn.Module):
             rec[i] = r.contiguous(memory_format=torch.channels_last)
 
         h0, w0 = spec.lowres_size(H, W, ds)
+        if u8 is not None:
+            return self._run_u8(ctx, src, rec, shapes, B, T, H, W, five, chunk, u8)
         if chunk:
             return self._run_chunk(ctx, src, rec, shapes, B, T, H, W, h0, w0, seg)
         oshape0 = (B, 1, h0, w0) if seg else (B, 3, H, W)
@@ -317,6 +328,27 @@ class MattingNetwork(nn.Module):
             ctx.forward(tb.data_ptr(), rin, o0.data_ptr(), o1.data_ptr(), [n.data_ptr() for n in new], False, stream)
             outs = [o0.view(T, B, 3, H, W).transpose(0, 1), o1.view(T, B, 1, H, W).transpose(0, 1)]
         return [*outs, *new]
+
+    def _run_u8(self, ctx, src, rec, shapes, B, T, H, W, five, chunk, u8):
+        mode, bgr = u8
+        if mode == native.COMPOSE_GREEN and bgr is None:
+            raise RuntimeError("forward_u8: COMPOSE_GREEN needs the background colour `bgr`")
+        dev, dt = src.device, src.dtype
+        C = 4 if mode == native.COMPOSE_RGBA else 3
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        tb = src.transpose(0, 1) if five else src.unsqueeze(0)         # [T,B,3,H,W]
+        if not tb.is_contiguous():
+            tb = tb.contiguous()
+        out = torch.empty((T, B, H, W, C), device=dev, dtype=torch.uint8)
+        steps = [(0, T)] if (chunk or T == 1) else [(t, 1) for t in range(T)]
+        for t0, _ in steps:
+            new = self._ring_next(self._static_ring(ctx, shapes, dev, dt), rec) if self._graph else \
+                [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
+            ctx.forward_u8(tb[t0].data_ptr(), [r.data_ptr() if r is not None else 0 for r in rec], out[t0].data_ptr(),
+                           [n.data_ptr() for n in new], mode, bgr, stream)
+            rec = new
+        frames = out.transpose(0, 1) if five else out[0]
+        return [frames, *rec]
 
     def _static_ring(self, ctx, shapes, dev, dt):
         key = (ctx.plan_key, dev, dt)

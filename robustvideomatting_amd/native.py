@@ -18,7 +18,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 # every symbol include/rvm_mi355x.h declares
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
-    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward",
+    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward", "rvm_forward_u8",
     "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
@@ -64,6 +64,8 @@ def lib():
     L.rvm_state_shape.restype = ci
     L.rvm_forward.argtypes = [vp, vp, cpp, vp, vp, cpp, ci, vp]
     L.rvm_forward.restype = ci
+    L.rvm_forward_u8.argtypes = [vp, vp, cpp, vp, cpp, ci, ctypes.POINTER(ctypes.c_float), vp]
+    L.rvm_forward_u8.restype = ci
     L.rvm_debug_tap.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64, i64p]
     L.rvm_debug_tap.restype = ci
     L.rvm_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ci, ctypes.POINTER(ci)]
@@ -200,6 +202,13 @@ class Context:
         check(lib().rvm_forward(self._h, ctypes.c_void_p(src_ptr), rin,
                                 ctypes.c_void_p(fgr_ptr) if fgr_ptr else None, ctypes.c_void_p(pha_ptr),
                                 rout, 1 if seg else 0, ctypes.c_void_p(stream)), "rvm_forward")
+
+    def forward_u8(self, src_ptr, r_in_ptrs, out_ptr, r_out_ptrs, mode, bgr, stream):
+        rin = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) if p else None for p in r_in_ptrs])
+        rout = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) for p in r_out_ptrs])
+        c3 = (ctypes.c_float * 3)(*(bgr if bgr is not None else (0.0, 0.0, 0.0)))
+        check(lib().rvm_forward_u8(self._h, ctypes.c_void_p(src_ptr), rin, ctypes.c_void_p(out_ptr), rout, mode, c3,
+                                   ctypes.c_void_p(stream)), "rvm_forward_u8")
 
     def launch_count(self):
         return lib().rvm_launch_count(self._h)

@@ -81,6 +81,46 @@ def test_compose_kernel_bytes_equal_reference_ops(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(72, 104), (61, 99)])          # W % 8 == 0 (vector stores) and an odd width (tail path)
+def test_forward_u8_bytes_equal_forward_then_compose(dtype, H, W):
+    """rvm_forward_u8 (composition + byte conversion inside the refiner's full-resolution kernel): the bytes
+    equal the reference's output ops applied to what forward returns, in every mode, frame by frame and as a chunk."""
+    from robustvideomatting_amd import MattingNetwork, native
+    params = synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=2)
+    m = MattingNetwork().eval()
+    m.load_state_dict(params)
+    m = m.to("cuda", dtype)
+    clip = synthetic.make_clip(3, H, W, seed=8, B=2).to("cuda", dtype)
+    bgr = [float(v) for v in torch.tensor([120, 255, 155], dtype=dtype).div(255)]
+    with torch.no_grad():
+        fgr, pha, *rec = m(clip, downsample_ratio=0.5)
+        for mode, kind in ((native.COMPOSE_GREEN, "video"), (native.COMPOSE_RGBA, "png_sequence"),
+                           (native.COMPOSE_ALPHA, None), (native.COMPOSE_FOREGROUND, None)):
+            got, *rec8 = m.forward_u8(clip, downsample_ratio=0.5, mode=mode, bgr=bgr)
+            assert got.dtype == torch.uint8 and got.shape[:4] == (2, 3, H, W)
+            f, p = fgr.cpu(), pha.cpu()
+            if kind is not None:
+                want = O.frames_to_u8(O.compose_frames(f.flatten(0, 1), p.flatten(0, 1), kind))
+            elif mode == native.COMPOSE_ALPHA:
+                want = O.frames_to_u8(p.flatten(0, 1).repeat(1, 3, 1, 1))
+            else:
+                want = O.frames_to_u8(f.flatten(0, 1))
+            assert torch.equal(got.cpu().flatten(0, 1), want), mode
+            for a, b in zip(rec, rec8):
+                assert torch.equal(a, b)
+        # frame by frame with carried states
+        r = [None] * 4
+        for t in range(3):
+            got, *r = m.forward_u8(clip[:, t], *r, downsample_ratio=0.5, mode=native.COMPOSE_GREEN, bgr=bgr)
+            want = O.frames_to_u8(O.compose_frames(fgr[:, t].cpu(), pha[:, t].cpu(), "video"))
+            assert got.shape == (2, H, W, 3)
+            assert (got.cpu().int() - want.int()).abs().max() <= 1           # chunked vs framewise tiles: rounding-level
+        with pytest.raises(RuntimeError, match="downsample_ratio == 1"):
+            m.forward_u8(clip[:, 0], downsample_ratio=1.0, mode=native.COMPOSE_ALPHA)
+
+
+@pytest.mark.gpu
 def test_convert_video_png_sequence_matches_oracle_pipeline(tmp_path):
     from robustvideomatting_amd import MattingNetwork
     T, H, W = 4, 64, 96
