@@ -154,15 +154,15 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     pha = torch.empty((batch * chunk, 1, wl["H"], wl["W"]), device=dev, dtype=tdt)
     if chunk > 1:
         src = clip.transpose(0, 1).contiguous()             # the native call takes time-major frames
-    acc = [0.0] * len(info)
-    reps = 20
+    samples = []
+    reps = 21
     for i in range(reps + 3):
         ms = ctx.profile_frame(src.data_ptr(), [t.data_ptr() for t in ra], fgr.data_ptr(), pha.data_ptr(),
                                [t.data_ptr() for t in rb], stream)
         ra, rb = rb, ra
         if i >= 3:
-            acc = [x + y for x, y in zip(acc, ms)]
-    avg = [x / reps for x in acc]
+            samples.append(ms)
+    avg = [sorted(col)[reps // 2] for col in zip(*samples)]      # median per launch: one stalled frame must not name the kernel
     k = max(range(len(info)), key=lambda i: avg[i])
     name, flops, nbytes = info[k]
     sec = avg[k] * 1e-3
@@ -176,7 +176,7 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
         roof = dict(bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=nbytes / sec / HBM_PEAK, traffic=None)
     roof.update(kernel=name, kernel_ms=avg[k], kernel_flops=flops, kernel_bytes=nbytes,
-                sum_kernel_ms=sum(avg), launches=len(info))
+                sum_kernel_ms=sum(avg), launches=len(info), kernels=sum(ctx.launch_kernels()))
     # HBM bytes of that launch from the committed rocprofv3 --pmc passes of this same command
     # (FETCH_SIZE + WRITE_SIZE, separate passes; DESIGN.md "Measurement" has the gfx950 calibration note)
     pmc = os.path.join(ROOT, PMC_FILES.get(wl_key, ""))
@@ -188,7 +188,8 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     if dump:
         os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
         with open(dump, "w") as f:
-            json.dump([dict(name=n, ms=m, flops=fl, bytes=by) for (n, fl, by), m in zip(info, avg)], f, indent=1)
+            json.dump([dict(name=n, ms=m, flops=fl, bytes=by, kernels=nk)
+                       for (n, fl, by), m, nk in zip(info, avg, ctx.launch_kernels())], f, indent=1)
     res["roofline"] = roof
     h, w = spec.lowres_size(wl["H"], wl["W"], ds)
     es = 4 if a.dtype == "fp32" else 2

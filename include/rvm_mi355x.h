@@ -138,8 +138,10 @@ int rvm_debug_tap(rvm_ctx* ctx, const char* name, float* host_out, int64_t capac
  * the product build reports *nlaunch = 0.  Synchronises the device.  Tuning aid, tools/stamp_table.py. */
 int rvm_debug_stamps(uint64_t* out, int capacity, int nlaunch[2]);
 
-/* Number of kernel launches one rvm_forward enqueues for the current plan. */
+/* Number of schedule entries (launches) one rvm_forward enqueues for the current plan. */
 int rvm_launch_count(const rvm_ctx* ctx);
+/* Kernels launch `index` of the schedule enqueues: 1, or 2 for a split-K convolution followed by its reduce pass. */
+int rvm_launch_kernels(const rvm_ctx* ctx, int index);
 
 /* Per-launch metadata (name, algorithmic FLOPs and bytes as defined in DESIGN.md) and a profiled
  * eager run that times every launch with hipEvents on `hip_stream` (synchronises). */

@@ -223,6 +223,7 @@ struct rvm_ctx {
         std::string name; double flops, bytes;     // algorithmic work of the launch
         std::function<void(hipStream_t, const FrameIO&)> fn;
         int edge;                                  // 1 / 2: first / last launches, the only ones that touch src / fgr / pha
+        int nk = 1;                                // kernels the launch enqueues (2: a split-K conv and its reduce pass)
     };
     std::vector<Launch> launches;
     std::map<std::string, Tap> taps;
@@ -696,7 +697,7 @@ int build_plan(rvm_ctx* c) {
     auto abuf = [&](size_t elems) { return (T*)c->arena_alloc(elems * es); };
     auto fbuf = [&](size_t elems) { return (float*)c->arena_alloc(elems * 4); };
     auto add = [&](const std::string& name, double flops, double bytes, std::function<void(hipStream_t, const FrameIO&)> f, int edge = 0) {
-        c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f), edge});
+        c->launches.push_back(rvm_ctx::Launch{name, flops, bytes, std::move(f), edge, 1});
     };
 
     // ---- recurrent state buffers.  16-bit I/O modes: the GRUs never read the caller's 16-bit tensors; the first launch
@@ -929,6 +930,7 @@ int build_plan(rvm_ctx* c) {
             else px_bytes += opx * probe.hC * (4 + es + es + (probe.out2_mode ? 2 : 0));          // z and h in, h' out (+ the caller's 16-bit copy)
         }
         add(name, 2.0 * B * Ho * Wo * KK * L.Cin * L.Cout, (double)B * px_bytes + KK * L.Cin * L.Cout * es, fn);
+        if (a.part) c->launches.back().nk = 2;
         return 0;
     };
 
@@ -1486,6 +1488,7 @@ int rvm_state_shape(const rvm_ctx* c, int level, int64_t shape[4]) {
 }
 
 int rvm_launch_count(const rvm_ctx* c) { return c ? (int)c->launches.size() : 0; }
+int rvm_launch_kernels(const rvm_ctx* c, int i) { return (c && i >= 0 && i < (int)c->launches.size()) ? c->launches[i].nk : 0; }
 
 int rvm_set_graph_mode(rvm_ctx* c, int enabled) {
     if (!c) return fail("rvm_set_graph_mode: null ctx");

@@ -19,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward", "rvm_forward_u8",
-    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_kernels", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def lib():
     L.rvm_metrics_static.restype = ci
     L.rvm_launch_count.argtypes = [vp]
     L.rvm_launch_count.restype = ci
+    L.rvm_launch_kernels.argtypes = [vp, ci]
+    L.rvm_launch_kernels.restype = ci
     L.rvm_launch_info.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double),
                                   ctypes.POINTER(ctypes.c_double)]
     L.rvm_launch_info.restype = ci
@@ -212,6 +214,10 @@ class Context:
 
     def launch_count(self):
         return lib().rvm_launch_count(self._h)
+
+    def launch_kernels(self):
+        """Kernels per schedule entry (2 for a split-K convolution + its reduce pass)."""
+        return [lib().rvm_launch_kernels(self._h, i) for i in range(self.launch_count())]
 
     def launch_info(self):
         """[(name, algorithmic_flops, algorithmic_bytes)] for the current plan."""

@@ -19,8 +19,14 @@ def main():
     as_json = "--json" in sys.argv
     launches = json.load(open(kjson))
     names = [k["name"] for k in launches]
-    n = len(names)
-    per = [defaultdict(list) for _ in range(n)]
+    nl = len(names)
+    owner = []                                                   # dispatch slot of a frame -> launch (a split-K conv + its reduce: 2 slots)
+    for i, k in enumerate(launches):
+        owner += [i] * k.get("kernels", 1)
+    n = len(owner)
+    per = [defaultdict(list) for _ in range(nl)]
+    adds = {"FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT",
+            "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"}
     for f in sorted(glob.glob(root + "/p*/*/*counter_collection.csv")):
         rows = defaultdict(dict)
         order = {}
@@ -34,11 +40,17 @@ def main():
                 order[d] = kn
         ids = sorted(rows)
         ids = ids[len(ids) % n:] if len(ids) % n else ids     # whole frames, counted from the end
-        for k, d in enumerate(ids):
-            for c, v in rows[d].items():
-                per[k % n][c].append(v)
+        nfr = len(ids) // n
+        for fr in range(nfr):
+            tot = [defaultdict(float) for _ in range(nl)]
+            for k in range(n):
+                for c, v in rows[ids[fr * n + k]].items():
+                    tot[owner[k]][c] += v                        # the kernels of one launch add up
+            for i in range(nl):
+                for c, v in tot[i].items():
+                    per[i][c].append(v)
     out = []
-    for i in range(n):
+    for i in range(nl):
         m = {c: sum(v) / len(v) for c, v in per[i].items()}
         e = dict(name=names[i], flops=launches[i]["flops"], bytes=launches[i]["bytes"], ms=launches[i]["ms"])
         e["fetch_bytes_raw"] = m.get("FETCH_SIZE", 0.0) * 1024
@@ -51,9 +63,21 @@ def main():
             e[c] = m.get(c, 0.0)
         e["gui_active"] = gui
         out.append(e)
+    # FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM: the counter can read 1/2 for wide coalesced reads): the refiner's
+    # full-resolution launch must read at least all of `src` (3 of the 7 full-resolution planes of its algorithmic
+    # bytes).  If the raw counter is below that, the doubled value brackets the known volume and is used for every launch
+    # of this workload; otherwise the raw value is.
+    factor, note = 1.0, "raw FETCH_SIZE (>= the known src read of dgf_apply_fullres)"
+    for e in out:
+        if e["name"] == "dgf_apply_fullres" and e["fetch_bytes_raw"] < 0.95 * e["bytes"] * 3.0 / 7.0:
+            factor, note = 2.0, "2 x FETCH_SIZE (raw is below the known src read of dgf_apply_fullres)"
+    for e in out:
+        e["fetch_bytes"] = factor * e["fetch_bytes_raw"]
+        e["fetch_note"] = note
     if as_json:
         print(json.dumps(out, indent=1))
         return
+    print("calibration: " + note)
     print("%-20s %10s %10s %10s %10s %8s %9s %9s" % ("launch", "alg_MB", "fetch_MB", "fetchx2_MB", "write_MB", "mfma%", "insts_mfma", "lds_confl"))
     tot = [0, 0, 0, 0]
     for e in out:

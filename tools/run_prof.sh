@@ -1,11 +1,11 @@
-# rocprofv3 kernel-trace + stats of the default bench command (run on the GPU box)
-#   MODE=graph|eager  WL=hd|4k  DT=fp16|fp16fast|fp32  TAG=name
+# rocprofv3 kernel-trace + stats of one bench command (run on the GPU box)
+#   MODE=eager|graph  WL=hd|4k|hd_resnet50  DT=fp16|fp16fast|fp32|bf16  BATCH  CHUNK  TAG=name
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-hd}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --mode ${MODE:-graph} --workload ${WL:-hd} --dtype ${DT:-fp16} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --dump-kernels $R/gpurun_out/prof_${TAG}_kernels.json > $R/gpurun_out/prof_${TAG}_stdout.txt 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --mode ${MODE:-eager} --workload ${WL:-hd} --dtype ${DT:-fp16} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --no-also --dump-kernels $R/gpurun_out/prof_${TAG}_kernels.json > $R/gpurun_out/prof_${TAG}_stdout.txt 2>&1
 echo exit=$?
 cd $R
 f=$(ls gpurun_out/prof_$TAG/*/*kernel_trace.csv | head -1)

@@ -17,7 +17,10 @@ def main():
     skip = int(sys.argv[4]) if len(sys.argv) > 4 else 25      # bench.py ends with ~23 event-timed eager frames
     names = [k["name"] for k in json.load(open(kjson))]
     info = {k["name"]: k for k in json.load(open(kjson))}
-    n = len(names)
+    nk = [k.get("kernels", 1) for k in json.load(open(kjson))]       # kernels per launch (split-K conv + reduce: 2)
+    first = [sum(nk[:i]) for i in range(len(nk))]
+    nl = len(names)
+    n = sum(nk)                                                      # dispatches per frame
     rows = []
     with open(trace) as f:
         for r in csv.DictReader(f):
@@ -29,21 +32,23 @@ def main():
     rows = rows[:len(rows) - skip * n]
     nf = min(frames, len(rows) // n - 1)
     rows = rows[len(rows) - nf * n:]
-    dur = [0.0] * n
-    gap = [0.0] * n
-    meta = [None] * n
+    dur = [0.0] * nl
+    gap = [0.0] * nl
+    meta = [None] * nl
     for fi in range(nf):
-        for i in range(n):
-            r = rows[fi * n + i]
-            dur[i] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / nf
-            if fi * n + i > 0:
-                p = rows[fi * n + i - 1]
-                gap[i] += (int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / nf
-            meta[i] = r
+        for i in range(nl):
+            for j in range(nk[i]):
+                r = rows[fi * n + first[i] + j]
+                dur[i] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / nf
+                if fi * n + first[i] + j > 0:
+                    p = rows[fi * n + first[i] + j - 1]
+                    gap[i] += (int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / nf
+                if j == 0:
+                    meta[i] = r
     span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / nf
     print("%d frames, %d launches/frame, frame span %.1f us, kernel sum %.1f us, gap sum %.1f us"
-          % (nf, n, span / 1e3, sum(dur) / 1e3, sum(gap) / 1e3))
-    for i in range(n):
+          % (nf, nl, span / 1e3, sum(dur) / 1e3, sum(gap) / 1e3))
+    for i in range(nl):
         r = meta[i]
         k = info[names[i]]
         wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
