@@ -240,6 +240,31 @@ struct rvm_ctx {
     struct GraphEntry { FrameIO key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
 
+    // Plans built earlier and not in use: a driver that alternates shapes (convert_video's short last chunk, 4-D and
+    // 5-D calls in turn) switches between them instead of re-allocating and re-measuring every time.  LRU, <= 4 parked.
+    struct Parked {
+        int B, T, H, W, h, w; double ds; int lh[5], lw[5];
+        char* arena; size_t arena_bytes, arena_used;
+        std::vector<Launch> launches; std::map<std::string, Tap> taps; std::map<std::string, int> tuned; std::vector<Tunable> tunable;
+        float* split_ws; size_t split_need; std::vector<GraphEntry> graphs;
+    };
+    std::vector<Parked> parked;                       // back = most recently used
+    void swap_plan(Parked& p) {
+        std::swap(B, p.B); std::swap(T, p.T); std::swap(H, p.H); std::swap(W, p.W); std::swap(h, p.h); std::swap(w, p.w);
+        std::swap(ds, p.ds);
+        for (int l = 0; l < 5; ++l) { std::swap(lh[l], p.lh[l]); std::swap(lw[l], p.lw[l]); }
+        std::swap(arena, p.arena); std::swap(arena_bytes, p.arena_bytes); std::swap(arena_used, p.arena_used);
+        launches.swap(p.launches); taps.swap(p.taps); tuned.swap(p.tuned); tunable.swap(p.tunable);
+        std::swap(split_ws, p.split_ws); std::swap(split_need, p.split_need); graphs.swap(p.graphs);
+    }
+    void free_parked() {
+        for (auto& p : parked) {
+            for (auto& g : p.graphs) (void)hipGraphExecDestroy(g.exec);
+            if (p.arena) (void)hipFree(p.arena);
+        }
+        parked.clear();
+    }
+
     size_t esize() const { return dtype == RVM_DTYPE_F16 ? 2 : 4; }          // internal element size
     const std::vector<float>* P(const std::string& n) const {
         auto it = params.find(n);
@@ -618,6 +643,8 @@ int finalize_impl(rvm_ctx* c) {
     c->planned = false;
     c->launches.clear();
     c->drop_graphs();
+    (void)hipDeviceSynchronize();
+    c->free_parked();                                   // plans hold pointers into the old weight blob
     return 0;
 }
 
@@ -1362,6 +1389,30 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (B < 1 || T < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
     if ((int64_t)B * T > 65535) return fail("rvm_plan: B*T exceeds the grid limit (65535)");
     if (!(ds > 0.0 && ds <= 1.0)) return fail("rvm_plan: downsample_ratio must be in (0, 1]");
+    if (c->planned && c->B == B && c->T == T && c->H == H && c->W == W && c->ds == ds) return 0;      // the active plan
+    // park the active plan, then look for the requested one among the parked
+    if (c->planned) {
+        rvm_ctx::Parked p{};
+        p.arena = nullptr; p.split_ws = nullptr;
+        c->swap_plan(p);                                // p <- active plan; active <- empty
+        c->parked.push_back(std::move(p));
+        c->planned = false;
+    }
+    for (size_t i = 0; i < c->parked.size(); ++i) {
+        rvm_ctx::Parked& p = c->parked[i];
+        if (p.B == B && p.T == T && p.H == H && p.W == W && p.ds == ds) {
+            c->swap_plan(p);
+            c->parked.erase(c->parked.begin() + (long)i);
+            c->planned = true;
+            return 0;
+        }
+    }
+    while (c->parked.size() > 4) {                      // least recently used first
+        HIPCHK(hipDeviceSynchronize());
+        for (auto& g : c->parked.front().graphs) (void)hipGraphExecDestroy(g.exec);
+        if (c->parked.front().arena) HIPCHK(hipFree(c->parked.front().arena));
+        c->parked.erase(c->parked.begin());
+    }
     c->B = B; c->T = T; c->H = H; c->W = W; c->ds = ds;
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
@@ -1369,7 +1420,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     c->lh[0] = c->h; c->lw[0] = c->w;
     for (int l = 1; l < 5; ++l) { c->lh[l] = (c->lh[l - 1] + 1) / 2; c->lw[l] = (c->lw[l - 1] + 1) / 2; }
     c->drop_graphs();
-    if (c->arena) { HIPCHK(hipFree(c->arena)); c->arena = nullptr; }
+    if (c->arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->arena)); c->arena = nullptr; }      // (a failed earlier plan)
     c->planned = false;
     c->tuned.clear();
     // sizing pass (arena == nullptr), then the real pass
@@ -1432,6 +1483,7 @@ void rvm_destroy(rvm_ctx* c) {
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->arena) (void)hipFree(c->arena);
+    c->free_parked();
     delete c;
 }
 

@@ -279,6 +279,28 @@ def test_chunked_clip_against_oracle(mode):
     assert s[0].shape == want[0].shape and (s[0].float().cpu() - want[0]).abs().max() < tol * 5
 
 
+def test_alternating_shapes_switch_between_kept_plans():
+    """A driver that alternates call shapes (convert_video's short last chunk; 4-D and 5-D calls in turn) switches between
+    plans the context keeps instead of re-planning: results are bit-identical to models that only ever saw one shape."""
+    from robustvideomatting_amd import synthetic
+    m, _ = _setup(torch.float16)
+    clip = synthetic.make_clip(4, 122, 218, seed=11).cuda().half()
+    other = synthetic.make_clip(2, 64, 96, seed=12).cuda().half()
+    refs = {}
+    with torch.no_grad():
+        for key, fn in (("a", lambda mm: mm(clip[:, 0], None, None, None, None, None, 0.25)),
+                        ("b", lambda mm: mm(clip[:, :3], None, None, None, None, None, 0.25)),
+                        ("c", lambda mm: mm(other[:, 0], None, None, None, None, None, 0.5))):
+            fresh, _ = _setup(torch.float16)
+            refs[key] = (fn, [t.clone() for t in fn(fresh)])
+        for rnd in range(3):
+            for key in ("a", "b", "c", "b", "a"):
+                fn, want = refs[key]
+                got = fn(m)
+                for x, y in zip(got, want):
+                    assert torch.equal(x, y), (rnd, key)
+
+
 def test_graph_replay_is_bit_identical_to_eager():
     from robustvideomatting_amd import synthetic
     me, _ = _setup(torch.float16)
