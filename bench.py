@@ -138,7 +138,8 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
             out = runner.step(src)
         sync_all()
         dt_local = time.perf_counter() - t0
-    fps, frames, dt = streams.aggregate_throughput(steps * batch * chunk, dt_local, dist, dev)
+    on_gloo = dist is not None and dist.get_backend() == "gloo"
+    fps, frames, dt = streams.aggregate_throughput(steps * batch * chunk, dt_local, dist, None if on_gloo else dev)
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
     res = dict(fps=fps, ms_per_step=dt / steps * 1e3, steps=steps, workload=wl["name"], streams_per_gpu=batch, chunk=chunk)
     if rank != 0:
@@ -227,12 +228,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal on a one-GPU box (RVM_BENCH_REHEARSE=1): every rank uses cuda:0 and the timing reduction runs over gloo
+    # (RCCL refuses two ranks on one device).  The data path is the same - it has no collective.
+    rehearse = os.environ.get("RVM_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
