@@ -501,15 +501,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (no clamps, no masks in the depthwise loop).
 // KSE = K steps of the fused expand (0: the input is already expanded), compile-time so that the number of loads
 // in flight is known where a tile is consumed (a run-time count makes every wait a wait for ALL loads)
-template <typename T, int K, int KSE, bool PJ = false>
+template <typename T, int K, int KSE, bool PJ = false, bool COLT = false>
 __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    // blockIdx.y = band x column tile (column tiles: frames too wide for a full-width LDS tile)
-    const int ncol = a.ncol > 1 ? a.ncol : 1;
-    const int slice = blockIdx.x, band = (int)blockIdx.y / ncol, ctile = (int)blockIdx.y - band * ncol, n = blockIdx.z;
-    const int ox0 = ncol > 1 ? ctile * a.cwt : 0, ox1 = ncol > 1 ? min(ox0 + a.cwt, a.Wo) : a.Wo;   // output columns of this tile
+    // COLT: blockIdx.y = band x column tile (frames too wide for a full-width LDS tile); else full-width bands (compile-time,
+    // so the common form keeps its contiguous-row addressing)
+    const int ncol = COLT ? a.ncol : 1;
+    const int slice = blockIdx.x, band = COLT ? (int)blockIdx.y / ncol : (int)blockIdx.y, ctile = COLT ? (int)blockIdx.y - band * ncol : 0, n = blockIdx.z;
+    const int ox0 = COLT ? ctile * a.cwt : 0, ox1 = COLT ? min(ox0 + a.cwt, a.Wo) : a.Wo;   // output columns of this tile
     const int TWo = ox1 - ox0;
     // a block owns a.cw channels: 16, or 8 for the already expanded layers whose grid would leave CUs idle
     const int c0 = slice * a.cw, cend = min(a.C, c0 + a.cw), nq = a.cw >> 2, nqlog = a.cw == 8 ? 1 : 2;
@@ -518,8 +519,8 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     const int trows = (r1 - r0 - 1) * a.stride + (K - 1) * a.dil + 1;
     const int in_lo = max(t_lo, 0), in_hi = min(t_lo + trows - 1, a.Hi - 1);
     const int tc_lo = ox0 * a.stride - a.pad;                        // input column of tile column 0 (may be negative)
-    const int PWt = (TWo - 1) * a.stride + (K - 1) * a.dil + 1;      // padded tile width
-    const int ic_lo = max(tc_lo, 0), ic_hi = min(tc_lo + PWt - 1, a.Wi - 1);
+    const int PWt = COLT ? (TWo - 1) * a.stride + (K - 1) * a.dil + 1 : a.Wi + 2 * a.pad;     // padded tile width
+    const int ic_lo = COLT ? max(tc_lo, 0) : 0, ic_hi = COLT ? min(tc_lo + PWt - 1, a.Wi - 1) : a.Wi - 1;
     const int TWi = ic_hi - ic_lo + 1;                               // real input columns of the tile
     const int NPX = (in_hi - in_lo + 1) * TWi;                       // real input pixels of the tile (rows of TWi)
     f32x4* ebuf = (f32x4*)smem;                                      // [4][npxs]
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(1024) void mbconv_ed(EdArgs a) {
     const T* xb = (const T*)a.x + (((size_t)n * a.Hi + in_lo) * a.Wi + ic_lo) * a.xs;
     const unsigned invW = TWi > 1 ? 0xFFFFFFFFu / (unsigned)TWi + 1u : 0u;    // px / TWi == umulhi(px, invW) for px < 2^16 (TWi == 1: see fdiv)
     auto fdiv = [](int p, unsigned inv) { return inv ? (int)__umulhi((unsigned)p, inv) : p; };   // inv == 0 <=> divisor 1
-    const bool fullw = TWi == a.Wi;                                  // the tile's input rows are one contiguous pixel range
+    const bool fullw = !COLT || TWi == a.Wi;                         // the tile's input rows are one contiguous pixel range
     auto tile_index = [&](int px) {                                  // flat tile pixel -> padded tile index
         const int iy = fdiv(px, invW), ix = px - iy * TWi;
         return (in_lo - t_lo + iy) * PWt + ix + (ic_lo - tc_lo);
@@ -753,8 +754,16 @@ template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t 
     dim3 grid((a.C + a.cw - 1) / a.cw, a.nband * (a.ncol > 1 ? a.ncol : 1), N);
     const size_t lds = ed_lds_bytes(K, a.KS, a.npxs, sizeof(T));
     const int kse = a.w ? a.KS : 0;                                  // 0..ED_KSMAX (host-checked)
-    if (a.pj_w) { hipLaunchKernelGGL((mbconv_ed<T, 3, 0, true>), grid, dim3(1024), lds, s, a); return; }      // block 1
-#define RVM_ED_CASE(KK, KS_) if (K == KK && kse == KS_) { hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); return; }
+    const bool colt = a.ncol > 1;
+    if (a.pj_w) {                                                    // block 1
+        if (colt) hipLaunchKernelGGL((mbconv_ed<T, 3, 0, true, true>), grid, dim3(1024), lds, s, a);
+        else hipLaunchKernelGGL((mbconv_ed<T, 3, 0, true>), grid, dim3(1024), lds, s, a);
+        return;
+    }
+#define RVM_ED_CASE(KK, KS_) if (K == KK && kse == KS_) { \
+        if (colt) hipLaunchKernelGGL((mbconv_ed<T, KK, KS_, false, true>), grid, dim3(1024), lds, s, a); \
+        else hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); \
+        return; }
     RVM_ED_CASE(3, 0) RVM_ED_CASE(3, 1) RVM_ED_CASE(3, 2) RVM_ED_CASE(3, 3)
     RVM_ED_CASE(5, 0) RVM_ED_CASE(5, 1) RVM_ED_CASE(5, 2) RVM_ED_CASE(5, 3)
 #undef RVM_ED_CASE
@@ -2644,13 +2653,16 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)dgf_apply<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-#define RVM_ED_ATTR(TT, KK) \
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define RVM_ED_ATTR1(TT, KK, KS_) \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define RVM_ED_ATTR(TT, KK) RVM_ED_ATTR1(TT, KK, 0) RVM_ED_ATTR1(TT, KK, 1) RVM_ED_ATTR1(TT, KK, 2) RVM_ED_ATTR1(TT, KK, 3)
     RVM_ED_ATTR(f16, 3) RVM_ED_ATTR(f16, 5) RVM_ED_ATTR(float, 3) RVM_ED_ATTR(float, 5) RVM_ED_ATTR(f32s, 3) RVM_ED_ATTR(f32s, 5)
 #undef RVM_ED_ATTR
+#undef RVM_ED_ATTR1
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 3, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<f16, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<float, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)mbconv_ed<f32s, 3, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
