@@ -1,5 +1,7 @@
 # PMC counter passes over one bench workload (one pass per run, counters only - no tracing)
 #   WL=hd|4k|hd_resnet50  TAG=name
+# RVM_AUTOTUNE=0: model-chosen tiles, so that the three passes (separate processes) run the very same kernel sequence
+export RVM_AUTOTUNE=0
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-hd}
 mkdir -p $R/gpurun_out/pmc_$TAG
