@@ -1305,32 +1305,46 @@ __global__ __launch_bounds__(256) void conv_split_reduce(ConvArgs a, long quads)
 
 // Waves of a conv_kxk block per source, in proportion to the loads the source's part of the halo patch takes
 // (the sources lie along a [0, 8) wave axis; a wave on a boundary stages both neighbours, one after the other).
-static void conv_assign_waves(ConvArgs& a, int PH, int PW) {
+static void conv_assign_waves(ConvArgs& a, int PH, int PW, int und) {
     if (a.nchunks > 1) {                                    // channel chunks cut across the sources: every wave stages every source
         for (int k = 0; k < a.nsrc; ++k) { a.src[k].w0 = 0; a.src[k].nw = 8; }
         return;
     }
-    double cost[4], total = 0;
+    // Whole waves per source, no wave shared between two sources (a shared wave stages them one after the other: two
+    // dependent round trips on the block's critical path).  A source's staging loop takes ceil(items / (threads x UN))
+    // rounds of loads (stage_source: UN = 2 items of 4 loads for a 2x2-block upsampled source, UN = `und` single loads for a
+    // direct one); of all ways to give the 8 waves to the sources take the one with the fewest rounds on the slowest
+    // source, then the fewest in total.
+    int items[4], un[4];
     for (int k = 0; k < a.nsrc; ++k) {
         const bool blocks = a.src[k].up && PH % 2 == 0 && PW % 2 == 0;
-        cost[k] = (double)(a.src[k].C / 4) * (blocks ? PH * PW : (a.src[k].up ? 4 : 1) * PH * PW) + 64;
-        total += cost[k];
+        items[k] = (a.src[k].C / 4) * (blocks ? (PH / 2) * (PW / 2) : PH * PW);
+        un[k] = a.src[k].up ? 2 : und;
     }
-    double at = 0;
-    for (int k = 0; k < a.nsrc; ++k) {
-        const double lo = at / total * 8, hi = (at + cost[k]) / total * 8;
-        int w0 = (int)(lo + 1e-6), w1 = (int)(hi - 1e-6) + 1;
-        if (w0 > 7) w0 = 7;
-        if (w1 > 8) w1 = 8;
-        if (w1 <= w0) w1 = w0 + 1;
-        a.src[k].w0 = w0; a.src[k].nw = w1 - w0;
-        at += cost[k];
-    }
+    int best[4] = {8, 0, 0, 0}, bestmax = 1 << 30, bestsum = 1 << 30, cur[4];
+    const int n = a.nsrc;
+    // compositions of 8 into n positive parts
+    for (int c0 = 1; c0 <= 8; ++c0)
+        for (int c1 = (n > 1 ? 1 : 0); c1 <= (n > 1 ? 8 : 0); ++c1)
+            for (int c2 = (n > 2 ? 1 : 0); c2 <= (n > 2 ? 8 : 0); ++c2) {
+                const int c3 = 8 - c0 - c1 - c2;
+                if (n > 3 ? c3 < 1 : c3 != 0) continue;
+                cur[0] = c0; cur[1] = c1; cur[2] = c2; cur[3] = c3;
+                int mx = 0, sum = 0;
+                for (int k = 0; k < n; ++k) {
+                    const int per = cur[k] * 64 * un[k];
+                    const int r = (items[k] + per - 1) / per;
+                    mx = r > mx ? r : mx; sum += r;
+                }
+                if (mx < bestmax || (mx == bestmax && sum < bestsum)) { bestmax = mx; bestsum = sum; for (int k = 0; k < 4; ++k) best[k] = cur[k]; }
+            }
+    int at = 0;
+    for (int k = 0; k < n; ++k) { a.src[k].w0 = at; a.src[k].nw = best[k]; at += best[k]; }
 }
 template <typename T, int MW, int NW, int KD, int S, int D, bool SPLITOK = false>
 static void launch_conv_t(const ConvArgs& a_, int N, hipStream_t s) {
     ConvArgs a = a_;
-    conv_assign_waves(a, ConvGeo<MW, KD, S, D>::PH, ConvGeo<MW, KD, S, D>::PW);
+    conv_assign_waves(a, ConvGeo<MW, KD, S, D>::PH, ConvGeo<MW, KD, S, D>::PW, 4);
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, a.part ? N * a.nchunks : N);
