@@ -125,6 +125,7 @@ struct ConvArgs {
     int Hi, Wi;                             // input size of the direct (non-upsampled) sources
     int CC, nchunks;                        // channel chunk staged per pass (multiple of 8), number of passes
     int SK, SKlog2;                         // K steps per weight stage in LDS (2, 4 or 8)
+    int wres;                               // conv_kxk: all KS x NW weight fragments resident in LDS (no stages)
     int cs, cd;                             // conv_sk only: stride and dilation (0 = 1)
     void* y; int Cout; int ys;              // EPI_RELU
     const void* hprev; int hC;              // GRU: previous state [N][H][W][hC] or null

@@ -934,6 +934,14 @@ int build_plan(rvm_ctx* c) {
                 fprintf(stderr, "[rvm] %-16s MW %d NW %d SK %d KS %d blocks %d lds %zu\n", name.c_str(), MW, NW, a.SK, L.KS, blocks,
                         conv_lds_bytes<T>(MW, NW, L.KD, cS, cD, L.CC, a.SK));
         }
+        // short-K layers: all weight fragments resident in LDS (conv_kxk WRES) when that keeps the blocks per CU the staged
+        // form has (two below 78 KB of LDS, one otherwise)
+        if (MW > 0 && geo == 0 && L.nchunks == 1 && !a.part && L.KS * NW <= 24 && !(getenv("RVM_WRES") && atoi(getenv("RVM_WRES")) == 0)) {
+            const size_t lw = conv_lds_bytes<T>(MW, NW, 3, 1, 1, L.CC, -L.KS), ls = conv_lds_bytes<T>(MW, NW, 3, 1, 1, L.CC, a.SK);
+            const bool same_occupancy = lw <= 52 * 1024 ? true : (lw <= 80 * 1024 ? ls > 52 * 1024 : (lw <= 150 * 1024 && ls > 80 * 1024));   // 2 x 80 KiB = the CU
+            if (same_occupancy) a.wres = 1;
+            if (getenv("RVM_VERBOSE") && c->arena) fprintf(stderr, "[rvm] %-16s wres %d (resident %zu B, staged %zu B)\n", name.c_str(), a.wres, lw, ls);
+        }
         const double KK = (double)L.KD * L.KD;
         auto fn = [=](hipStream_t st, const FrameIO& io) {
             ConvArgs b = a; fill(b, io);

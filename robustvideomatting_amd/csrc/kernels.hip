@@ -206,6 +206,32 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi[i], x.hi[i], acc, 0, 0, 0);
 }
 
+// MW x NW accumulators against NW weight and MW pixel fragments, TERM-major for the split type: the three MFMAs of one
+// accumulator are dependent (each waits ~2 issue slots for the previous); issued accumulator by accumulator they stall,
+// issued term by term every MFMA has MW * NW - 1 independent ones between itself and its predecessor.
+template <int MW, int NW>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[MW][NW], const Frag<f32s> (&w)[NW], const Frag<f32s> (&x)[MW]) {
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].lo, x[mi].hi, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].lo, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].hi, acc[mi][ni], 0, 0, 0);
+}
+template <typename T, int MW, int NW>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[MW][NW], const Frag<T> (&w)[NW], const Frag<T> (&x)[MW]) {
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], w[ni], x[mi]);
+}
+
 __device__ __forceinline__ float act_f(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
@@ -914,11 +940,12 @@ template <int MW, int KD, int S, int D> struct ConvGeo {
 // LDS of one conv_kxk block: halo patch + double-buffered weight stages (SK K-steps x NW n-tiles)
 constexpr int CONV_NT = 512;                                // threads per conv_kxk block
 constexpr int CONV_SKMAX = 8;                               // K steps per weight stage: 2, 4 or 8 (ConvArgs::SK)
+// SK > 0: double-buffered weight stages of SK steps; SK < 0: all -SK steps resident (conv_kxk WRES)
 template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK) {
     const int PH = (4 * MW - 1) * S + (KD - 1) * D + 1, PW = 15 * S + (KD - 1) * D + 1;
     size_t patch = (size_t)PH * PW * (CC + Tr<T>::kLdsPad) * sizeof(T);
     if (patch < (size_t)MW * NW * 4096) patch = (size_t)MW * NW * 4096;     // the K-group reduction reuses the patch area
-    return patch + (size_t)2 * SK * NW * 512 * sizeof(T);
+    return patch + (size_t)(SK < 0 ? -SK : 2 * SK) * NW * 512 * sizeof(T);
 }
 template size_t conv_lds_bytes<f16>(int, int, int, int, int, int, int);
 template size_t conv_lds_bytes<float>(int, int, int, int, int, int, int);
@@ -1041,7 +1068,10 @@ __device__ __forceinline__ void stage_source(T* patch, const ConvSrc S, int q_lo
 // The concatenated input channels are processed in chunks of a.CC channels (one chunk for the
 // mobilenetv3 decoder; several for the resnet50 layers whose halo patch would not fit LDS);
 // K index inside a chunk = tap * chunk_channels + channel.
-template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false>
+// WRES: ALL of the block's weight fragments (KS steps x NW n-tiles, host-checked to be small) are copied into LDS once, by
+// LDS-DMA (global_load_lds, no staging registers), while the patch is staged; the K loop then runs without weight stages
+// and without barriers.  For the short-K decoder convs, whose barrier-paced stages each cost a global round trip.
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false, bool WRES = false>
 __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs a) {   // 20-row tiles: one block per CU (LDS), registers to spare
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1108,7 +1138,22 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
             if (j < NP) *(f32x4*)((char*)(wbuf + (size_t)buf * WSTAGE) + (size_t)(tid + CONV_NT * j) * 16) = wr[j];
     };
     const int KSfull = ((KK * a.CC + 31) / 32 + 7) / 8 * 8;   // K steps of a full channel chunk (several chunks: padded to 8)
-    wload(chunk0 * KSfull);                                 // in flight while the patch is staged
+    if constexpr (WRES) {
+        // fragments of n-tiles nt0 .. nt0 + NW - 1 are contiguous in the weight blob ([NT][KS][512]) and keep that order in
+        // LDS; a wave-instruction moves 64 consecutive 16-byte pieces (an odd last tile repeats tile NT - 1: never used)
+        const int per_tile = a.KS * PPS, npc = NW * per_tile;
+        const int swv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (int i0 = swv * 64; i0 < npc; i0 += CONV_NT) {
+            const int i = i0 + (tid & 63);
+            const int ni = i / per_tile, rem = i - ni * per_tile;
+            const int tile = min(nt0 + ni, a.NT - 1);
+            const char* g = (const char*)a.w + ((size_t)tile * per_tile + rem) * 16;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                             (void __attribute__((address_space(3)))*)((char*)wbuf + (size_t)i0 * 16), 16, 0, 0);
+        }
+    } else {
+        wload(chunk0 * KSfull);                             // in flight while the patch is staged
+    }
 
     f32x4 acc[MW][NW];
 #pragma unroll
@@ -1151,7 +1196,7 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
                     for (int cch = used; cch < CCc; cch += 4) stp4(patch + pp * CSL, cch, f32x4{0, 0, 0, 0});
             }
         }
-        if (chunk == chunk0) wstore(0);
+        if constexpr (!WRES) { if (chunk == chunk0) wstore(0); }
         // Every load so far has landed (the LDS stores above used them) except, as far as the compiler can tell, the
         // padding loads of partly filled staging rounds; say so, or it guards the first register reuse in the K loop
         // with a vmcnt(0) that also waits for the weight stage in flight, on every K step.
@@ -1163,6 +1208,26 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
         const int NQ8 = CCc >> 3;
         int tap = 0, c8 = g + 4 * kgrp;                          // K group 1 starts one step in
         while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+        if constexpr (WRES) {
+            for (int p = kgrp; p < KSc; p += 2) {
+                const int tp = min(tap, KK - 1);            // K tail: weights are zero there, keep the read in-bounds
+                const int dy = tp / KD, dx = tp - dy * KD;
+                const T* pb = patch + ((wave * S + dy * D) * PW + l15 * S + dx * D) * CSL + c8 * 8;
+                Frag<T> xf[MW], wf[NW];
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi) xf[mi].load_lds(pb + (4 * mi * S) * PW * CSL);
+#pragma unroll
+                for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wbuf + (size_t)(ni * a.KS + p) * 512, lane);
+                mma_tile(acc, wf, xf);
+                // all fragment reads of the step first, then the MFMAs back to back (left alone the scheduler reads one
+                // pixel fragment, waits for it and issues its three dependent MFMAs, four times per step)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MW + NW) * (sizeof(T) == 4 ? 1 : 1), 0);   // DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NW, 0);                                // MFMA
+                c8 += 8;                                    // two K steps on
+                while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
+            }
+            __syncthreads();                                // the patch area is reused below
+        } else
         for (int ks0 = 0; ks0 < ((a.dbg & 2) ? 0 : KSc); ks0 += SK) {
             const bool more = (splitk ? ks0 + SK < KSc : gs + SK < a.KS) && !(a.dbg & 8);
             if (more) wload(gs + SK);
@@ -1177,10 +1242,9 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
                     for (int mi = 0; mi < MW; ++mi) xf[mi].load_lds(pb + (4 * mi * S) * PW * CSL);
 #pragma unroll
                     for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wst + (ni * SK + p) * 512, lane);
-#pragma unroll
-                    for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], wf[ni], xf[mi]);
+                    mma_tile(acc, wf, xf);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MW + NW), 0);    // the step's fragment reads first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NW, 0);      // ... then its MFMAs back to back (see the WRES loop)
                 }
                 c8 += 8;                                    // two K steps on
                 while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
@@ -1341,14 +1405,17 @@ static void conv_assign_waves(ConvArgs& a, int PH, int PW, int und) {
     int at = 0;
     for (int k = 0; k < n; ++k) { a.src[k].w0 = at; a.src[k].nw = best[k]; at += best[k]; }
 }
-template <typename T, int MW, int NW, int KD, int S, int D, bool SPLITOK = false>
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLITOK = false, bool WRESOK = false>
 static void launch_conv_t(const ConvArgs& a_, int N, hipStream_t s) {
     ConvArgs a = a_;
     conv_assign_waves(a, ConvGeo<MW, KD, S, D>::PH, ConvGeo<MW, KD, S, D>::PW, 4);
     const int TH = 4 * MW;
     const int tiles_y = (a.H + TH - 1) / TH;
     dim3 grid(a.tiles_x * tiles_y, (a.NT + NW - 1) / NW, a.part ? N * a.nchunks : N);
-    const size_t lds = conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.SK);
+    const size_t lds = conv_lds_bytes<T>(MW, NW, KD, S, D, a.CC, a.wres ? -a.KS : a.SK);
+    if constexpr (WRESOK) {
+        if (a.wres) { hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D, false, true>), grid, dim3(CONV_NT), lds, s, a); return; }
+    }
     if constexpr (SPLITOK) {
         if (a.part) {
             hipLaunchKernelGGL((conv_kxk<T, MW, NW, KD, S, D, true>), grid, dim3(CONV_NT), lds, s, a);
@@ -1606,11 +1673,11 @@ template <typename T> void launch_conv3(const ConvArgs& a, int N, int MW, int NW
     if (MW == 5 && NW == 4) launch_conv_t<T, 5, 4, 3, 1, 1, true>(a, N, s);
     else if (MW == 5 && NW == 1) launch_conv_t<T, 5, 1, 3, 1, 1, true>(a, N, s);
     else if (MW == 5 && NW == 2) launch_conv_t<T, 5, 2, 3, 1, 1, true>(a, N, s);
-    else if (MW == 4 && NW == 1) launch_conv_t<T, 4, 1, 3, 1, 1>(a, N, s);
-    else if (MW == 2 && NW == 2) launch_conv_t<T, 2, 2, 3, 1, 1, true>(a, N, s);
-    else if (MW == 2 && NW == 1) launch_conv_t<T, 2, 1, 3, 1, 1, true>(a, N, s);
-    else if (MW == 1 && NW == 2) launch_conv_t<T, 1, 2, 3, 1, 1, true>(a, N, s);
-    else launch_conv_t<T, 1, 1, 3, 1, 1>(a, N, s);
+    else if (MW == 4 && NW == 1) launch_conv_t<T, 4, 1, 3, 1, 1, false, true>(a, N, s);
+    else if (MW == 2 && NW == 2) launch_conv_t<T, 2, 2, 3, 1, 1, true, true>(a, N, s);
+    else if (MW == 2 && NW == 1) launch_conv_t<T, 2, 1, 3, 1, 1, true, true>(a, N, s);
+    else if (MW == 1 && NW == 2) launch_conv_t<T, 1, 2, 3, 1, 1, true, true>(a, N, s);
+    else launch_conv_t<T, 1, 1, 3, 1, 1, false, true>(a, N, s);
 }
 template void launch_conv3<f16>(const ConvArgs&, int, int, int, int, hipStream_t);
 template void launch_conv3<float>(const ConvArgs&, int, int, int, int, hipStream_t);
@@ -2646,12 +2713,14 @@ template void launch_maxpool<f16>(const MaxPoolArgs&, int, hipStream_t);
 template void launch_maxpool<float>(const MaxPoolArgs&, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false> static void conv_attr() {
-    (void)hipFuncSetAttribute((const void*)conv_kxk<T, MW, NW, KD, S, D, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <typename T, int MW, int NW, int KD, int S, int D, bool SPLIT = false, bool WRES = false> static void conv_attr() {
+    (void)hipFuncSetAttribute((const void*)conv_kxk<T, MW, NW, KD, S, D, SPLIT, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename T> static void conv_attr_all() {
     conv_attr<T, 4, 1, 3, 1, 1>(); conv_attr<T, 2, 2, 3, 1, 1>(); conv_attr<T, 2, 1, 3, 1, 1>();
     conv_attr<T, 1, 2, 3, 1, 1>(); conv_attr<T, 1, 1, 3, 1, 1>();
+    conv_attr<T, 4, 1, 3, 1, 1, false, true>(); conv_attr<T, 2, 2, 3, 1, 1, false, true>(); conv_attr<T, 2, 1, 3, 1, 1, false, true>();
+    conv_attr<T, 1, 2, 3, 1, 1, false, true>(); conv_attr<T, 1, 1, 3, 1, 1, false, true>();
     conv_attr<T, 1, 2, 3, 2, 1>(); conv_attr<T, 1, 2, 3, 1, 2>(); conv_attr<T, 1, 2, 7, 2, 1>();
     conv_attr<T, 5, 1, 3, 1, 1>(); conv_attr<T, 5, 2, 3, 1, 1>(); conv_attr<T, 5, 1, 3, 1, 2>(); conv_attr<T, 5, 2, 3, 1, 2>();
     conv_attr<T, 5, 1, 3, 1, 1, true>(); conv_attr<T, 5, 2, 3, 1, 1, true>(); conv_attr<T, 5, 1, 3, 1, 2, true>(); conv_attr<T, 5, 2, 3, 1, 2, true>();
