@@ -2112,12 +2112,12 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     for (int rd = 0; rd < 2; ++rd) {
         const int mt0 = wave + 12 * rd;
         int pp[3], py[3], px[3];
-        f32x4 acc[3];
+        f32x4 acc[3][1];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             pp[u] = min((mt0 + 4 * u) * 16 + lx, 323);
             py[u] = pp[u] / 18; px[u] = pp[u] - py[u] * 18;
-            acc[u] = f32x4{0, 0, 0, 0};
+            acc[u][0] = f32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
@@ -2126,12 +2126,12 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
             Frag<TC> xf[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) xf[u].load_lds(patch + ((py[u] + dy) * 20 + px[u] + dx) * CSL + c8 * 8);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) mma(acc[u], cwf[ks], xf[u]);
+            const Frag<TC> w1[1] = {cwf[ks]};
+            mma_tile(acc, w1, xf);                                              // term-major over the three tiles
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            f32x4 v = acc[u] + cb;
+            f32x4 v = acc[u][0] + cb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (float)(T)fmaxf(v[r], 0.f);       // as it would come back from memory
             hv_[rd][u] = v;
@@ -2220,19 +2220,47 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g);
     const f32x4 z4 = f32x4{0, 0, 0, 0};
     f32x4 A = z4;
+    {
+        // the four tiles layer by layer, each layer's three MFMA terms across the four tiles: a tile's nine MFMAs are one
+        // dependent chain, the tiles are independent of each other
+        f32x4 m[4];
+        HL8 in[4];
+        auto layer = [&](const f16* w, int wstride) {
+            f16x8 wh[4], wlo[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const HL8 in = (g == t) ? split8(cov, var) : split8(hs[t][0], hs[t][1]);
-        f32x4 acc = mma_hl(z4, wl + t * 1024, lane, in);
-        acc += b1;
+            for (int t = 0; t < 4; ++t) {
+                const f16* wf = w + t * wstride;
+                wh[t] = *(const f16x8*)(wf + lane * 8); wlo[t] = *(const f16x8*)(wf + 512 + lane * 8);
+                m[t] = z4;
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-        acc = mma_hl(z4, wl + 4 * 1024, lane, split8(acc, z4));
-        acc += b2;
+            for (int t = 0; t < 4; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[t], in[t].hi, m[t], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-        acc = mma_hl(z4, wl + (5 + t) * 1024, lane, split8(acc, z4));
-        if (g == t) A = acc;
+            for (int t = 0; t < 4; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], in[t].lo, m[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], in[t].hi, m[t], 0, 0, 0);
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) in[t] = (g == t) ? split8(cov, var) : split8(hs[t][0], hs[t][1]);
+        layer(wl, 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 v = m[t] + b1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            in[t] = split8(v, z4);
+        }
+        layer(wl + 4 * 1024, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 v = m[t] + b2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            in[t] = split8(v, z4);
+        }
+        layer(wl + 5 * 1024, 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (g == t) A = m[t];
     }
     A += f32x4{wt.b3[0], wt.b3[1], wt.b3[2], wt.b3[3]};
     const int gy = y0 + ly;
