@@ -1039,7 +1039,7 @@ int build_plan(rvm_ctx* c) {
                 // 1/16 scale, whose halo forbids bands) the expand runs as its own full-chip GEMM instead and
                 // the fused kernel starts from the expanded tensor (16-channel slices, no redundancy).
                 const size_t xbytes = (size_t)rows_for(rb) * tin_for(cwt) * curC * es;
-                bool fuse_e = b.has_expand && b.expand.KS <= 3 && !(xbytes > 160 * 1024 && !getenv("RVM_ED_ALWAYS_FUSE"));
+                bool fuse_e = b.has_expand && b.expand.KS <= 4 && !(xbytes > 160 * 1024 && !getenv("RVM_ED_ALWAYS_FUSE"));
                 if (b.has_expand && !fuse_e) {
                     T* e = abuf((size_t)B * Hi * Wi * exp);
                     pw("mb" + std::to_string(i + 1) + ".expand", b.expand, cur, curC, Hi * Wi, e, exp, nullptr, nullptr, 0, nullptr, nullptr);
@@ -1054,7 +1054,7 @@ int build_plan(rvm_ctx* c) {
                 a.rb = rb; a.nband = cdiv(Ho, rb); a.npxs = rup(trows_for(rb) * tcols_for(cwt), 16);
                 a.cwt = cwt; a.ncol = ncol;
                 { const char* e = getenv("RVM_DBG"); a.dbg = e ? atoi(e) >> 4 : 0; }
-                if (a.KS > 3 || rup(rb * std::min(cwt, Wo), 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * tin_for(cwt) >= 65536 || (b.has_se && b.se.S > 1024))
+                if (a.KS > 4 || rup(rb * std::min(cwt, Wo), 64) > 4096 || lds_for(rb) > 160 * 1024 || rows_for(rb) * tin_for(cwt) >= 65536 || (b.has_se && b.se.S > 1024))
                     return fail("mbconv_ed: unsupported block shape");
                 // an already expanded layer with few 16-channel blocks (the 1/16-scale layers: <= 60 on 256 CUs) splits
                 // into 8-channel blocks: half the depthwise work per block, twice the CUs

@@ -503,7 +503,7 @@ template void launch_pw<f32s>(const PwArgs&, int, int, hipStream_t);
 //      [channel quad][pixel][4] so the depthwise reads are conflict-free.
 //   D: a wave owns one channel quad (uniform weights, LDS broadcast) x 64 consecutive output pixels.
 // ------------------------------------------------------------------------------------------
-[[maybe_unused]] constexpr int ED_KSMAX = 3;                                  // fused expand: Cin <= 96 (wider layers expand in their own GEMM)
+[[maybe_unused]] constexpr int ED_KSMAX = 4;                                  // fused expand: Cin <= 128 (wider layers expand in their own GEMM; 5 steps spill)
 size_t ed_lds_bytes(int K, int KS, int npxs, int es) {
     return (size_t)4 * npxs * 16 + (size_t)KS * 512 * es + (size_t)(K * K * 16 + 32 + 16) * 4 + 4096;
 }
@@ -790,8 +790,8 @@ template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t 
         if (colt) hipLaunchKernelGGL((mbconv_ed<T, KK, KS_, false, true>), grid, dim3(1024), lds, s, a); \
         else hipLaunchKernelGGL((mbconv_ed<T, KK, KS_>), grid, dim3(1024), lds, s, a); \
         return; }
-    RVM_ED_CASE(3, 0) RVM_ED_CASE(3, 1) RVM_ED_CASE(3, 2) RVM_ED_CASE(3, 3)
-    RVM_ED_CASE(5, 0) RVM_ED_CASE(5, 1) RVM_ED_CASE(5, 2) RVM_ED_CASE(5, 3)
+    RVM_ED_CASE(3, 0) RVM_ED_CASE(3, 1) RVM_ED_CASE(3, 2) RVM_ED_CASE(3, 3) RVM_ED_CASE(3, 4)
+    RVM_ED_CASE(5, 0) RVM_ED_CASE(5, 1) RVM_ED_CASE(5, 2) RVM_ED_CASE(5, 3) RVM_ED_CASE(5, 4)
 #undef RVM_ED_CASE
 }
 template void launch_ed<f16>(const EdArgs&, int, int, hipStream_t);
@@ -2767,7 +2767,7 @@ void kernels_init() {
 #define RVM_ED_ATTR1(TT, KK, KS_) \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define RVM_ED_ATTR(TT, KK) RVM_ED_ATTR1(TT, KK, 0) RVM_ED_ATTR1(TT, KK, 1) RVM_ED_ATTR1(TT, KK, 2) RVM_ED_ATTR1(TT, KK, 3)
+#define RVM_ED_ATTR(TT, KK) RVM_ED_ATTR1(TT, KK, 0) RVM_ED_ATTR1(TT, KK, 1) RVM_ED_ATTR1(TT, KK, 2) RVM_ED_ATTR1(TT, KK, 3) RVM_ED_ATTR1(TT, KK, 4)
     RVM_ED_ATTR(f16, 3) RVM_ED_ATTR(f16, 5) RVM_ED_ATTR(float, 3) RVM_ED_ATTR(float, 5) RVM_ED_ATTR(f32s, 3) RVM_ED_ATTR(f32s, 5)
 #undef RVM_ED_ATTR
 #undef RVM_ED_ATTR1
