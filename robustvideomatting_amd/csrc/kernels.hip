@@ -206,23 +206,50 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi[i], x.hi[i], acc, 0, 0, 0);
 }
 
-// MW x NW accumulators against NW weight and MW pixel fragments, TERM-major for the split type: the three MFMAs of one
-// accumulator are dependent (each waits ~2 issue slots for the previous); issued accumulator by accumulator they stall,
-// issued term by term every MFMA has MW * NW - 1 independent ones between itself and its predecessor.
+// MW x NW accumulators against NW weight and MW pixel fragments for the split type.  The three MFMAs of one accumulator
+// are a dependent chain; issued accumulator by accumulator they stall on each other and on the fragment reads (what the
+// compiler schedules when left alone: read one pixel fragment, wait, three dependent MFMAs, next fragment ...).  Here the
+// accumulators are taken in groups of >= 4 (GM pixel fragments x NW), each group term by term, and the scheduler is
+// told to put the fragment reads of group i + 1 in front of the MFMAs of group i (sched_group_barrier: 0x100 = DS read,
+// 0x008 = MFMA), so reads overlap MFMAs inside one wave and no MFMA waits for its predecessor.
+template <int MW, int NW> struct MmaGroups { static constexpr int GM = NW >= 4 ? 1 : (NW >= 2 ? 2 : MW); };
 template <int MW, int NW>
 __device__ __forceinline__ void mma_tile(f32x4 (&acc)[MW][NW], const Frag<f32s> (&w)[NW], const Frag<f32s> (&x)[MW]) {
+    constexpr int GM = MmaGroups<MW, NW>::GM;
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
+    for (int m0 = 0; m0 < MW; m0 += GM) {
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].lo, x[mi].hi, acc[mi][ni], 0, 0, 0);
+        for (int mi = m0; mi < m0 + GM && mi < MW; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
+            for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].lo, x[mi].hi, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].lo, acc[mi][ni], 0, 0, 0);
+        for (int mi = m0; mi < m0 + GM && mi < MW; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
+            for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].lo, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].hi, acc[mi][ni], 0, 0, 0);
+        for (int mi = m0; mi < m0 + GM && mi < MW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni].hi, x[mi].hi, acc[mi][ni], 0, 0, 0);
+    }
+}
+// the schedule that goes with it: call right after mma_tile in a K step whose fragments come from LDS (two ds_read_b128 each)
+template <typename T, int MW, int NW> __device__ __forceinline__ void mma_tile_schedule() {
+    if constexpr (std::is_same<T, f32s>::value) {
+        constexpr int GM = MmaGroups<MW, NW>::GM;
+        constexpr int g0 = GM < MW ? GM : MW;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NW + 2 * g0, 0);            // all weight fragments + the first group's pixels
+#pragma unroll
+        for (int m0 = 0; m0 < MW; m0 += GM) {
+            const int cur = (MW - m0) < GM ? (MW - m0) : GM;
+            const int nxt = m0 + GM < MW ? ((MW - m0 - GM) < GM ? (MW - m0 - GM) : GM) : 0;
+            if (nxt == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (nxt == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else if (nxt > 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * 5, 0);
+            if (cur == 1) __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);
+            else if (cur == 2) __builtin_amdgcn_sched_group_barrier(0x008, 6 * NW, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW * MW, 0);
+        }
+    }
 }
 template <typename T, int MW, int NW>
 __device__ __forceinline__ void mma_tile(f32x4 (&acc)[MW][NW], const Frag<T> (&w)[NW], const Frag<T> (&x)[MW]) {
@@ -1219,10 +1246,7 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
 #pragma unroll
                 for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wbuf + (size_t)(ni * a.KS + p) * 512, lane);
                 mma_tile(acc, wf, xf);
-                // all fragment reads of the step first, then the MFMAs back to back (left alone the scheduler reads one
-                // pixel fragment, waits for it and issues its three dependent MFMAs, four times per step)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MW + NW) * (sizeof(T) == 4 ? 1 : 1), 0);   // DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NW, 0);                                // MFMA
+                mma_tile_schedule<T, MW, NW>();
                 c8 += 8;                                    // two K steps on
                 while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
             }
@@ -1243,8 +1267,7 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
 #pragma unroll
                     for (int ni = 0; ni < NW; ++ni) wf[ni].loadw(wst + (ni * SK + p) * 512, lane);
                     mma_tile(acc, wf, xf);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MW + NW), 0);    // the step's fragment reads first ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NW, 0);      // ... then its MFMAs back to back (see the WRES loop)
+                    mma_tile_schedule<T, MW, NW>();
                 }
                 c8 += 8;                                    // two K steps on
                 while (c8 >= NQ8) { c8 -= NQ8; ++tap; }
