@@ -1755,10 +1755,22 @@ template <typename T, typename TIO, bool STEM>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
     if constexpr (sizeof(TIO) == 2 && sizeof(T) == 4) {
-        if ((int)blockIdx.x >= a.nblk) {                             // whole block
-            if (blockIdx.y == 0) state_prep<TIO>(a.sp, (int)blockIdx.x - a.nblk, threadIdx.x);
+        if ((int)blockIdx.x >= a.nblk) {                             // whole block: the state blocks are spread over the samples' rows of the grid
+            const int sb = ((int)blockIdx.x - a.nblk) * (int)gridDim.y + (int)blockIdx.y;
+            if (sb < a.sp.blocks) state_prep<TIO>(a.sp, sb, threadIdx.x);
             return;
         }
+    }
+    // stem weights (27 x 16) and bias through LDS: read per (tap, channel) in the conv loop below, 27 dependent global loads
+    // per wave otherwise
+    [[maybe_unused]] __shared__ __attribute__((aligned(16))) float stem_lds[27 * 16 + 16];
+    if constexpr (STEM) {
+        const int t = threadIdx.x;
+        const float w0 = a.stem_w[t], w1 = a.stem_w[min(t + 256, 431)], b0 = a.stem_b[t & 15];
+        stem_lds[t] = w0;
+        if (t + 256 < 432) stem_lds[t + 256] = w1;
+        if (t < 16) stem_lds[432 + t] = b0;
+        __syncthreads();
     }
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, n = blockIdx.y;
     if (wv >= a.h3 * a.w3) return;                                   // whole wave
@@ -1799,7 +1811,8 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     if constexpr (STEM) {
         if (lane < 9) { hy = 8 * y3 - 1; hx = 8 * x3 - 1 + lane; }
         else if (lane < 17) { hy = 8 * y3 + (lane - 9); hx = 8 * x3 - 1; }
-        hv = interp(hy, hx);
+        hv = f32x4{0, 0, 0, 0};
+        if (lane < 17) hv = interp(hy, hx);                          // 17 of 64 lanes: the other lanes issue no halo loads
     }
     o[3] = (float)(T)((o[0] + o[1] + o[2]) / 3.f);
     if (inb) st4f((T*)a.s0 + (((size_t)n * a.h + oy) * a.w + ox) * 4, o);
@@ -1883,7 +1896,7 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         const int p16 = lane >> 2, oq = lane & 3, py = p16 >> 2, px = p16 & 3;
         float acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = a.stem_b[oq * 4 + q];
+        for (int q = 0; q < 4; ++q) acc[q] = stem_lds[432 + oq * 4 + q];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1891,7 +1904,7 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
                 const f32x4 v = tile[(2 * py + ky) * 9 + 2 * px + kx];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const f32x4 w = *(const f32x4*)(a.stem_w + ((ky * 3 + kx) * 3 + c) * 16 + oq * 4);
+                    const f32x4 w = *(const f32x4*)(stem_lds + ((ky * 3 + kx) * 3 + c) * 16 + oq * 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] += v[c] * w[q];
                 }
@@ -1909,7 +1922,7 @@ template <typename T> void launch_down(const DownArgs& a_, int N, int io, hipStr
     DownArgs a = a_;
     a.nblk = (a.h3 * a.w3 + 3) / 4;
     if (sizeof(T) != 4 || !io) a.sp.blocks = 0;
-    const dim3 grid(a.nblk + a.sp.blocks, N);
+    const dim3 grid(a.nblk + (a.sp.blocks + N - 1) / N, N);
     if constexpr (sizeof(T) == 4) {
         if (io == IO_F16) {
             if (a.stem_y) hipLaunchKernelGGL((downsample<T, f16, true>), grid, dim3(256), 0, s, a);
