@@ -68,6 +68,8 @@ struct PwArgs {
     // instead of a gemv launch: scale = hardsigmoid(fc2(relu(xscale * sum of fc1 partials + b1)) + b2); in_scale == null
     const float* se_hpart; int se_nparts, se_S; float se_xscale;    // partial fc1 pre-activations [N][nparts][S]
     const float* se_b1; const void* se_w2 /* T [Cin][S] */; const float* se_b2;
+    // pw_gemm_lds split-K: K steps in `nsplit` slices over blockIdx.z, raw partial sums [nsplit][N][HW][NT*16], reduce pass
+    float* part; int nsplit;
 };
 
 // ---- fused expand (1x1, MFMA) -> depthwise k x k (LDS) [-> squeeze-excite fc1 partial] -----------

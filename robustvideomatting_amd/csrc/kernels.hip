@@ -499,8 +499,166 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
     stamp(2);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same 1x1 conv as an LDS-tiled GEMM: block tile 64 pixels x 64 channels, K in steps of 32, both operands through
+// LDS (pixels staged through registers - they are converted to the (hi, lo) form on the way; weight fragments by LDS-DMA,
+// one n-tile per wave), double-buffered, one barrier per step, optional split-K over blockIdx.z with a fixed-order
+// reduce pass.  pw_gemm loads fragments straight into registers, each wave its own: fine where the layer is bound by
+// launch latency, but for resnet50's wide 1x1 layers at 1/16 scale (M = 510, K / N = 512 ... 2048) every wave pulls its
+// operands through L2 separately (32 x 32 tiles: M N K 4 / 16 bytes).  64 x 64 tiles shared through LDS halve that.
+// Candidate beside the pw_gemm configurations; picked by plan-time measurement.  No SE input scale, no SE tail.
+// ------------------------------------------------------------------------------------------
+template <typename T> constexpr int pwl_csl() { return 32 + Tr<T>::kLdsPad; }
+template <typename T> constexpr size_t pwl_lds_bytes() { return (size_t)2 * (64 * pwl_csl<T>() + 4 * 512) * sizeof(T); }
+template <typename T>
+__global__ __launch_bounds__(256) void pw_gemm_lds(PwArgs a) {
+    [[maybe_unused]] Stamper stamp;
+    extern __shared__ __attribute__((aligned(16))) char pwl_smem[];
+    constexpr int CSL = pwl_csl<T>();
+    constexpr int ABUF = 64 * CSL, WBUF = 4 * 512;                   // elements per buffer
+    T* Ab = (T*)pwl_smem;                                            // [2][64][CSL]
+    T* Wb = Ab + 2 * ABUF;                                           // [2][4][512]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+    const int n = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - n * nsplit;
+    const int mt0 = blockIdx.x * 4, nt0 = blockIdx.y * 4;
+    const int per = (a.KS + nsplit - 1) / nsplit, ks_lo = zs * per, ks_hi = min(a.KS, ks_lo + per);
+    // pixel operand: thread loads quads (px = i >> 3, q = i & 7) for i = tid, tid + 256
+    const T* xsrc[2]; bool xok[2]; int xq[2], xpx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j;
+        xpx[j] = i >> 3; xq[j] = i & 7;
+        const int pix = mt0 * 16 + xpx[j];
+        xok[j] = pix < a.HW;
+        size_t ipix = (size_t)n * a.HW + (xok[j] ? pix : 0);
+        if (a.sstride > 1) {
+            const int oy = (xok[j] ? pix : 0) / a.sWo, ox = (xok[j] ? pix : 0) - oy * a.sWo;
+            ipix = (size_t)n * a.sHi * a.sWi + (size_t)oy * a.sstride * a.sWi + ox * a.sstride;
+        }
+        xsrc[j] = (const T*)a.x + ipix * a.xs + xq[j] * 4;
+    }
+    // weight operand: wave w moves n-tile nt0 + w (clamped: an absent tile repeats the last one and is never stored)
+    const char* wsrc = (const char*)a.w + (size_t)min(nt0 + wave, a.NT - 1) * a.KS * 512 * sizeof(T);
+    constexpr int WPI = 512 * sizeof(T) / 16 / 64;                   // LDS-DMA instructions per fragment (2, or 1 for fp16)
+    f32x4 xr[2];
+    auto issue = [&](int ks, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = xok[j] && ks * 32 + xq[j] * 4 < a.Cin;
+            xr[j] = ld4f(ok ? xsrc[j] + ks * 32 : (const T*)a.x);
+            if (!ok) xr[j] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < WPI; ++k)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + ((size_t)ks * 512 * sizeof(T)) + (size_t)(k * 64 + lane) * 16),
+                                             (void __attribute__((address_space(3)))*)((char*)(Wb + buf * WBUF + wave * 512) + k * 1024), 16, 0, 0);
+    };
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+    if (ks_lo < ks_hi) issue(ks_lo, 0);
+    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+        const int buf = (ks - ks_lo) & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stp4(Ab + buf * ABUF + xpx[j] * CSL, xq[j] * 4, xr[j]);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this step's weight fragments have landed in LDS
+        __syncthreads();
+        if (ks + 1 < ks_hi) issue(ks + 1, buf ^ 1);
+        Frag<T> xf[2], wf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) xf[mi].load_lds(Ab + buf * ABUF + ((2 * wm + mi) * 16 + l15) * CSL + g * 8);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) wf[ni].loadw(Wb + buf * WBUF + (2 * wn + ni) * 512, lane);
+        mma_tile(acc, wf, xf);
+    }
+    stamp(1);
+    // ---- epilogue: lane holds channels ch..ch+3 of pixel pix (as in pw_gemm)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int nt = nt0 + 2 * wn + ni;
+        if (nt >= a.NT) continue;
+        const int ch = nt * 16 + g * 4;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int mt = mt0 + 2 * wm + mi;
+            const int pix = mt * 16 + l15;
+            const bool ok = mt < a.MT && pix < a.HW && ch < a.Cout;
+            if (a.part) {                                            // split-K: raw partial sums [slice][N][HW][NT * 16]
+                if (mt < a.MT && pix < a.HW)
+                    *(f32x4*)(a.part + (((size_t)zs * (gridDim.z / nsplit) + n) * a.HW + pix) * (a.NT * 16) + ch) = acc[mi][ni];
+                continue;
+            }
+            f32x4 v = acc[mi][ni] + *(const f32x4*)(a.bias + ch);
+            if (!a.act_post) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+            }
+            if (ok) {
+                if (a.res) v += ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + ch);
+                if (a.act_post) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+                }
+                if (a.out_scale) v *= *(const f32x4*)(a.out_scale + (size_t)n * a.oss + min(ch, a.Cout - 4));
+                st4f((T*)a.y + ((size_t)n * a.HW + pix) * a.ys + ch, v);
+            }
+            if (a.pool) {
+                f32x4 sm = ok ? v : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm[r] += __shfl_xor(sm[r], m);
+                }
+                if (l15 == 0 && mt < a.MT) *(f32x4*)(a.pool + ((size_t)n * a.MT + mt) * (a.NT * 16) + ch) = sm;
+            }
+        }
+    }
+    stamp(2);
+}
+// second pass of a split-K pw_gemm_lds launch: partial sums added in slice order, then pw_gemm's epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void pw_split_reduce(PwArgs a, long quads) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const int CQ = a.Cout >> 2, NC = a.NT * 16;
+    const long pix = i / CQ;                                         // n * HW + pixel
+    const int ch = (int)(i - pix * CQ) * 4;
+    const size_t per = (size_t)(quads / CQ) * NC;
+    const float* p = a.part + (size_t)pix * NC + ch;
+    f32x4 v = *(const f32x4*)(a.bias + ch), t[4];
+    for (int c0 = 0; c0 < a.nsplit; c0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *(const f32x4*)(p + (size_t)min(c0 + k, a.nsplit - 1) * per);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (c0 + k < a.nsplit) v += t[k];
+    }
+    if (!a.act_post) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+    }
+    if (a.res) v += ld4f((const T*)a.res + (size_t)pix * a.rs + ch);
+    if (a.act_post) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
+    }
+    st4f((T*)a.y + (size_t)pix * a.ys + ch, v);
+}
+
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    if (cfg >= 7) {                                                  // LDS-tiled form (a.nsplit, a.part set by the host for split-K)
+        const int ns = a.nsplit > 1 ? a.nsplit : 1;
+        hipLaunchKernelGGL((pw_gemm_lds<T>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N * ns), dim3(256), pwl_lds_bytes<T>(), s, a);
+        if (a.part) {
+            const long quads = (long)N * a.HW * (a.Cout / 4);
+            hipLaunchKernelGGL((pw_split_reduce<T>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
+        }
+        return;
+    }
     const size_t lds = (a.in_scale || a.se_hpart) ? (size_t)a.KS * 32 * sizeof(T) + (a.se_hpart ? (256 + 32) * 4 : 0) : 0;   // the SE scale vector (+ SE tail scratch)
     switch (cfg) {
         case 0: hipLaunchKernelGGL((pw_gemm<T, 2, 2, 2, 2, 1>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N), dim3(256), lds, s, a); break;

@@ -183,6 +183,22 @@ def test_column_tiled_depthwise_forced_on_a_small_frame(gc, monkeypatch):
     assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
 
 
+@pytest.mark.parametrize("cfg", ["7", "9"])
+def test_lds_tiled_pointwise_gemm_forced(gc, monkeypatch, cfg):
+    """pw_gemm_lds (64 x 64 tiles through LDS, weight fragments by LDS-DMA; cfg 9: split-K in four slices + reduce pass) is
+    normally one of the candidates plan-time measurement chooses from; forced here on every 1x1 layer that admits it, both
+    variants (resnet50: strided 1x1, residual + ReLU after the add, pooled sums for the LR-ASPP gate)."""
+    monkeypatch.setenv("RVM_PW_CFG", cfg)
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+    w = gc.run("fp32", H=122, W=218, ds=0.5, T=2, B=2, variant="resnet50", verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=150, W=201, ds=0.8, T=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    w = gc.run("fp16fast", H=122, W=218, ds=0.25, T=2, variant="resnet50", verbose=False)
+    assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
+
+
 def test_fp32_1080p_at_ratio_one():
     """1920x1080 at downsample_ratio=1: the low-res map is the full frame, wider than any full-width LDS tile of the
     depthwise kernel (column tiles) - the largest shape the reference runs on common inputs."""
