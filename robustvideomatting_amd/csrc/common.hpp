@@ -70,6 +70,7 @@ struct PwArgs {
     const float* se_b1; const void* se_w2 /* T [Cin][S] */; const float* se_b2;
     // pw_gemm_lds split-K: K steps in `nsplit` slices over blockIdx.z, raw partial sums [nsplit][N][HW][NT*16], reduce pass
     float* part; int nsplit;
+    int nsamp, w_major;                // pw_gemm_lds (set by launch_pw): samples in the launch; tile order for the XCD-aware mapping
 };
 
 // ---- fused expand (1x1, MFMA) -> depthwise k x k (LDS) [-> squeeze-excite fc1 partial] -----------

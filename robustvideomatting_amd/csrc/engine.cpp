@@ -796,20 +796,21 @@ int build_plan(rvm_ctx* c) {
         a.y = y; a.Cout = L.Cout; a.ys = ys; a.pool = pool; a.HW = HW; a.MT = cdiv(HW, 16); a.NT = L.NT; a.act = L.act;
         if (in_scale && (L.KS * 32 > 1024 || L.Cin % 4)) { fail("pw_gemm: input scale vector too long"); plan_bad = true; return; }
         if (ex.se_hpart && (in_scale || L.Cin > 256 || ex.se_S > 32 || ex.se_S % 4 || ex.se_nparts > 256)) { fail("pw_gemm: squeeze-excite tail too large for the prologue"); plan_bad = true; return; }
-        // candidates: pw_gemm configurations 0..6; for layers without a squeeze-excite input scale also the LDS-tiled form
-        // (7) and, where the epilogue is plain, its split-K variants in 2 / 4 / 8 slices (8, 9, 10).  The latency model only
-        // knows 0..6; the others are taken where plan-time measurement finds them faster.
+        // candidates: pw_gemm configurations 0..6; for layers without a squeeze-excite input scale also the LDS-tiled
+        // pipelined form with 64-pixel block tiles (7) and, where the epilogue is plain, its split-K variants in 2 / 4 / 8
+        // slices (8, 9, 10), then the same with 128-pixel tiles (11; split 2 / 4: 12, 13).  The latency model only knows
+        // 0..6; the others are taken where plan-time measurement finds them faster.
         const bool lds_ok = !in_scale && !ex.se_hpart;
         const bool split_ok = lds_ok && !pool && !out_scale && (int64_t)B * 8 <= 65535;
-        const int ncand = lds_ok ? (split_ok ? 11 : 8) : 7;
+        const int ncand = lds_ok ? (split_ok ? 14 : 8) : 7;
         int cfg = tune_pick(name, ncand, pick_pw_cfg(a.MT, a.NT, a.KS, B));
         if (const char* e = getenv("RVM_PW_CFG")) {               // test hook: force one configuration wherever it is a candidate
             const int v = atoi(e);
             if (v >= 0 && v < ncand) cfg = v;
         }
-        if (cfg >= 8) {
-            a.nsplit = 1 << (cfg - 7);
-            if (a.KS < 2 * a.nsplit) { cfg = 7; a.nsplit = 0; }      // too few K steps to slice: the unsplit form
+        if (cfg >= 8 && cfg != 11) {
+            a.nsplit = cfg >= 12 ? 1 << (cfg - 11) : 1 << (cfg - 7);
+            if (a.KS < 2 * a.nsplit) { cfg = cfg >= 12 ? 11 : 7; a.nsplit = 0; }      // too few K steps to slice: the unsplit form
             else {
                 a.part = (float*)1;                                 // marker: the launch takes c->split_ws
                 c->split_need = std::max(c->split_need, (size_t)a.nsplit * B * HW * L.NT * 16 * sizeof(float));

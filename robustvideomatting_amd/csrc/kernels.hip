@@ -500,81 +500,163 @@ __global__ __launch_bounds__(256) void pw_gemm(PwArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The same 1x1 conv as an LDS-tiled GEMM: block tile 64 pixels x 64 channels, K in steps of 32, both operands through
-// LDS (pixels staged through registers - they are converted to the (hi, lo) form on the way; weight fragments by LDS-DMA,
-// one n-tile per wave), double-buffered, one barrier per step, optional split-K over blockIdx.z with a fixed-order
-// reduce pass.  pw_gemm loads fragments straight into registers, each wave its own: fine where the layer is bound by
-// launch latency, but for resnet50's wide 1x1 layers at 1/16 scale (M = 510, K / N = 512 ... 2048) every wave pulls its
-// operands through L2 separately (32 x 32 tiles: M N K 4 / 16 bytes).  64 x 64 tiles shared through LDS halve that.
-// Candidate beside the pw_gemm configurations; picked by plan-time measurement.  No SE input scale, no SE tail.
+// The same 1x1 conv as an LDS-tiled, software-pipelined GEMM (fp32-stored activations: the float and f32s types):
+// block tile (64 MW) pixels x 64 channels, 8 waves as 4 (pixels) x 2 (channels), each MW x 2 MFMA tiles, K in steps of
+// 32.  BOTH operands reach LDS by LDS-DMA (global_load_lds, 16 bytes per lane) into a ring of PWL_NS stages, PWL_NS - 1
+// of them in flight, one barrier per K step.  The pixels land raw and are turned into MFMA fragments when read (the
+// (hi, lo) split of the f32s type happens in registers); the 16-byte pieces of a pixel row are rotated by a
+// row-dependent amount so that fragment reads (one pixel row per lane, 128-byte row pitch) spread over all banks
+// (pwl_rot; the DMA's LDS side is contiguous per wave-instruction, so the permutation is applied to the SOURCE address
+// of each lane - still one 128-byte line per 8 lanes).  Weight fragments land in their lane-linear order.
+// Inside a wave the K loop is skewed by one step: the fragment reads of step k are issued, then the MFMAs of step k - 1
+// run while they are in flight, then the new fragments are converted.  (Measured on the unskewed loop: 0.29 us per K
+// step with the operand loads switched off against 0.08 us for the loads alone - LDS reads, conversions and MFMAs of
+// the two waves of a SIMD ran one after the other, in step behind the barrier.)
+// All LDS reads of the K loop are inline asm with their own s_waitcnt: left to the compiler, every LDS read after an
+// LDS-DMA gets a vmcnt(0) in front (it cannot tell the ring's stages apart), which would drain the pipeline at every step.
+// Blocks are mapped to tiles XCD-aware (see below); optional split-K with a fixed-order reduce pass.  pw_gemm loads
+// fragments straight into registers, each wave its own: fine where the layer is bound by launch latency, but for
+// resnet50's wide 1x1 layers at 1/16 scale (M = 510, K / N = 512 ... 2048) every wave pulls its operands through L2
+// separately and only three K steps deep.  Candidate beside the pw_gemm configurations; picked by plan-time measurement.
+// No SE input scale, no SE tail.
 // ------------------------------------------------------------------------------------------
-template <typename T> constexpr int pwl_csl() { return 32 + Tr<T>::kLdsPad; }
-template <typename T> constexpr size_t pwl_lds_bytes() { return (size_t)2 * (64 * pwl_csl<T>() + 4 * 512) * sizeof(T); }
-template <typename T>
-__global__ __launch_bounds__(256) void pw_gemm_lds(PwArgs a) {
+constexpr int PWL_NS = 6, PWL_NTH = 512;
+template <int MW> constexpr int pwl_stage_bytes() { return 64 * MW * 128 + 4 * 2048; }
+template <int MW> constexpr size_t pwl_lds_bytes() { return (size_t)PWL_NS * pwl_stage_bytes<MW>(); }
+// rotation of a row's eight pieces: over the 16 rows x 2 lane groups one ds_read_b128 serves together, the pieces then
+// fall into 16 different 16-byte bank sets (rows r and r + 2 share a bank set at a 128-byte pitch)
+__device__ __forceinline__ int pwl_rot(int row) { return (row >> 1) & 5; }
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {           // result valid after lds_wait() on it
+    f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v;
+}
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ void pwl_frag(Frag<f32s>& f, f32x4 p0, f32x4 p1) { f.hi = __builtin_bit_cast(f16x8, p0); f.lo = __builtin_bit_cast(f16x8, p1); }
+__device__ __forceinline__ void pwl_frag(Frag<float>& f, f32x4 p0, f32x4 p1) { f.lo = p0; f.hi = p1; }
+
+template <typename T, int MW>
+__global__ __launch_bounds__(PWL_NTH) void pw_gemm_lds(PwArgs a) {
+    static_assert(sizeof(T) == 4, "fp32-stored activations only");
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char pwl_smem[];
-    constexpr int CSL = pwl_csl<T>();
-    constexpr int ABUF = 64 * CSL, WBUF = 4 * 512;                   // elements per buffer
-    T* Ab = (T*)pwl_smem;                                            // [2][64][CSL]
-    T* Wb = Ab + 2 * ABUF;                                           // [2][4][512]
+    constexpr int NS = PWL_NS, BM = 64 * MW, ABYTES = BM * 128, STAGE = pwl_stage_bytes<MW>(), NI = MW + 1;   // NI: LDS-DMA instructions per thread and stage
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
-    const int n = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - n * nsplit;
-    const int mt0 = blockIdx.x * 4, nt0 = blockIdx.y * 4;
+    // Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share an L2): XCD class c = b % 8 takes the c-th eighth of
+    // the tiles in an order in which neighbours share operands - (sample, K slice, channel block, pixel block) with the
+    // pixel blocks fastest where the weights are the larger operand (an XCD then pulls 1/8 of the weights + the pixels
+    // instead of all the weights), channel blocks fastest otherwise.  1-D grid of 8 * ceil(tiles / 8) blocks.
+    const int mblks = (a.MT + 4 * MW - 1) / (4 * MW), nblks = (a.NT + 3) / 4;
+    const int tiles = mblks * nblks * nsplit * a.nsamp, per_xcd = (tiles + 7) >> 3;
+    int t = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (t >= tiles) return;
+    int mb, nb;
+    if (a.w_major) { mb = t % mblks; t /= mblks; nb = t % nblks; t /= nblks; }
+    else { nb = t % nblks; t /= nblks; mb = t % mblks; t /= mblks; }
+    const int zs = t % nsplit, n = t / nsplit;
+    const int mt0 = mb * (4 * MW), nt0 = nb * 4;
     const int per = (a.KS + nsplit - 1) / nsplit, ks_lo = zs * per, ks_hi = min(a.KS, ks_lo + per);
-    // pixel operand: thread loads quads (px = i >> 3, q = i & 7) for i = tid, tid + 256
-    const T* xsrc[2]; bool xok[2]; int xq[2], xpx[2];
+    const int wm = wave & 3, wn = wave >> 2;
+    // ---- epilogue operands requested first (oldest in the vector-memory queue: the K loop's counted waits cover them)
+    f32x4 e_bias[2], e_res[MW][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = tid + 256 * j;
-        xpx[j] = i >> 3; xq[j] = i & 7;
-        const int pix = mt0 * 16 + xpx[j];
-        xok[j] = pix < a.HW;
-        size_t ipix = (size_t)n * a.HW + (xok[j] ? pix : 0);
+    for (int ni = 0; ni < 2; ++ni) {
+        const int ch = min(nt0 + 2 * wn + ni, a.NT - 1) * 16 + g * 4;
+        e_bias[ni] = *(const f32x4*)(a.bias + ch);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            e_res[mi][ni] = f32x4{0, 0, 0, 0};
+            if (a.res && !a.part) {
+                const int pix = min((mt0 + MW * wm + mi) * 16 + l15, a.HW - 1);
+                e_res[mi][ni] = ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + min(ch, a.Cout - 4));
+            }
+        }
+    }
+    // ---- DMA sources.  Pixel operand: piece i = tid + 512 j sits in LDS slot i (row i / 8, rotated piece i % 8)
+    const char* asrc[MW]; int ach[MW];
+#pragma unroll
+    for (int j = 0; j < MW; ++j) {
+        const int i = tid + PWL_NTH * j, row = i >> 3, p = ((i & 7) - pwl_rot(row)) & 7;
+        const int pix = min(mt0 * 16 + row, a.HW - 1);                  // rows past the map repeat the last pixel (never stored)
+        size_t ipix = (size_t)n * a.HW + pix;
         if (a.sstride > 1) {
-            const int oy = (xok[j] ? pix : 0) / a.sWo, ox = (xok[j] ? pix : 0) - oy * a.sWo;
+            const int oy = pix / a.sWo, ox = pix - oy * a.sWo;
             ipix = (size_t)n * a.sHi * a.sWi + (size_t)oy * a.sstride * a.sWi + ox * a.sstride;
         }
-        xsrc[j] = (const T*)a.x + ipix * a.xs + xq[j] * 4;
+        ach[j] = p * 4;
+        asrc[j] = (const char*)((const float*)a.x + ipix * a.xs + ach[j]);
     }
-    // weight operand: wave w moves n-tile nt0 + w (clamped: an absent tile repeats the last one and is never stored)
-    const char* wsrc = (const char*)a.w + (size_t)min(nt0 + wave, a.NT - 1) * a.KS * 512 * sizeof(T);
-    constexpr int WPI = 512 * sizeof(T) / 16 / 64;                   // LDS-DMA instructions per fragment (2, or 1 for fp16)
-    f32x4 xr[2];
-    auto issue = [&](int ks, int buf) {
+    // weight operand: piece tid of the stage's 4 fragments (an absent n-tile repeats the last one and is never stored)
+    const char* wsrc = (const char*)a.w + (size_t)min(nt0 + (tid >> 7), a.NT - 1) * a.KS * 2048 + (tid & 127) * 16;
+    auto issue = [&](int ks, int st) {
+        char* sb = pwl_smem + st * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = xok[j] && ks * 32 + xq[j] * 4 < a.Cin;
-            xr[j] = ld4f(ok ? xsrc[j] + ks * 32 : (const T*)a.x);
-            if (!ok) xr[j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < MW; ++j) {
+            const bool okc = ks * 32 + ach[j] < a.Cin;                  // pieces past Cin: any valid address (zeroed / masked where used)
+            const char* src = okc ? asrc[j] + (size_t)ks * 128 : (const char*)a.x;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(sb + (PWL_NTH * j + wave * 64) * 16), 16, 0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < WPI; ++k)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + ((size_t)ks * 512 * sizeof(T)) + (size_t)(k * 64 + lane) * 16),
-                                             (void __attribute__((address_space(3)))*)((char*)(Wb + buf * WBUF + wave * 512) + k * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + (size_t)ks * 2048),
+                                         (void __attribute__((address_space(3)))*)(sb + ABYTES + wave * 1024), 16, 0, 0);
     };
-    const int wm = wave & 1, wn = wave >> 1;
-    f32x4 acc[2][2];
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)pwl_smem;
+    // fragment read addresses inside stage 0
+    unsigned aoff[MW][2], woff[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MW; ++mi) {
+        const int row = (MW * wm + mi) * 16 + l15, rot = pwl_rot(row);
+        aoff[mi][0] = lbase + row * 128 + ((2 * g + rot) & 7) * 16;
+        aoff[mi][1] = lbase + row * 128 + ((2 * g + 1 + rot) & 7) * 16;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) woff[ni] = lbase + ABYTES + (2 * wn + ni) * 2048 + lane * 16;
+    f32x4 acc[MW][2];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
-    if (ks_lo < ks_hi) issue(ks_lo, 0);
-    for (int ks = ks_lo; ks < ks_hi; ++ks) {
-        const int buf = (ks - ks_lo) & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) stp4(Ab + buf * ABUF + xpx[j] * CSL, xq[j] * 4, xr[j]);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this step's weight fragments have landed in LDS
-        __syncthreads();
-        if (ks + 1 < ks_hi) issue(ks + 1, buf ^ 1);
-        Frag<T> xf[2], wf[2];
+    for (int s = 0; s < NS - 1; ++s)
+        if (ks_lo + s < ks_hi) issue(ks_lo + s, s);
+    int st = 0;
+    Frag<T> xf[2][MW], wf[2][2];                                     // [set]: the fragments being multiplied / being read
+    // one K step: reads of step ks into set `in`, MFMAs of step ks - 1 out of set `out` while they fly, conversion
+    auto step = [&](int ks, Frag<T> (&xi)[MW], Frag<T> (&wi)[2], const Frag<T> (&xo)[MW], const Frag<T> (&wo)[2]) {
+        // stage ks has landed once at most the NS - 2 stages issued after it are outstanding (fewer exist near the end)
+        if (ks + NS - 2 < ks_hi) wait_vm<NI * (NS - 2)>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                                // everyone's pieces are in; everyone has read stage ks - 1
+        if (ks + NS - 1 < ks_hi) issue(ks + NS - 1, st == 0 ? NS - 1 : st - 1);
+        const unsigned so = st * STAGE;
+        f32x4 wr[2][2], xr[MW][2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) xf[mi].load_lds(Ab + buf * ABUF + ((2 * wm + mi) * 16 + l15) * CSL + g * 8);
+        for (int ni = 0; ni < 2; ++ni) { wr[ni][0] = lds_read16(woff[ni] + so); wr[ni][1] = lds_read16(woff[ni] + so + 1024); }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) wf[ni].loadw(Wb + buf * WBUF + (2 * wn + ni) * 512, lane);
-        mma_tile(acc, wf, xf);
+        for (int mi = 0; mi < MW; ++mi) { xr[mi][0] = lds_read16(aoff[mi][0] + so); xr[mi][1] = lds_read16(aoff[mi][1] + so); }
+        if (ks > ks_lo) mma_tile(acc, wo, xo);
+        lds_wait(wr[0][0], wr[0][1], wr[1][0], wr[1][1]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) pwl_frag(wi[ni], wr[ni][0], wr[ni][1]);
+        const bool tail = ks * 32 + 32 > a.Cin && ks * 32 + g * 8 >= a.Cin;     // the last, partial K step: lanes past Cin hold whatever was there
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            lds_wait(xr[mi][0], xr[mi][1]);
+            XRaw<T> x; x.a = xr[mi][0]; x.b = xr[mi][1];
+            xi[mi] = x.frag();
+            if (tail) xi[mi].zero();
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+    };
+    int ks = ks_lo;
+    for (; ks + 1 < ks_hi; ks += 2) {
+        step(ks, xf[0], wf[0], xf[1], wf[1]);
+        step(ks + 1, xf[1], wf[1], xf[0], wf[0]);
     }
+    if (ks < ks_hi) { step(ks, xf[0], wf[0], xf[1], wf[1]); mma_tile(acc, wf[0], xf[0]); }
+    else if (ks_lo < ks_hi) mma_tile(acc, wf[1], xf[1]);
     stamp(1);
     // ---- epilogue: lane holds channels ch..ch+3 of pixel pix (as in pw_gemm)
 #pragma unroll
@@ -583,22 +665,22 @@ __global__ __launch_bounds__(256) void pw_gemm_lds(PwArgs a) {
         if (nt >= a.NT) continue;
         const int ch = nt * 16 + g * 4;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int mt = mt0 + 2 * wm + mi;
+        for (int mi = 0; mi < MW; ++mi) {
+            const int mt = mt0 + MW * wm + mi;
             const int pix = mt * 16 + l15;
             const bool ok = mt < a.MT && pix < a.HW && ch < a.Cout;
             if (a.part) {                                            // split-K: raw partial sums [slice][N][HW][NT * 16]
                 if (mt < a.MT && pix < a.HW)
-                    *(f32x4*)(a.part + (((size_t)zs * (gridDim.z / nsplit) + n) * a.HW + pix) * (a.NT * 16) + ch) = acc[mi][ni];
+                    *(f32x4*)(a.part + (((size_t)zs * a.nsamp + n) * a.HW + pix) * (a.NT * 16) + ch) = acc[mi][ni];
                 continue;
             }
-            f32x4 v = acc[mi][ni] + *(const f32x4*)(a.bias + ch);
+            f32x4 v = acc[mi][ni] + e_bias[ni];
             if (!a.act_post) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
             }
             if (ok) {
-                if (a.res) v += ld4f((const T*)a.res + ((size_t)n * a.HW + pix) * a.rs + ch);
+                if (a.res) v += e_res[mi][ni];
                 if (a.act_post) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], a.act);
@@ -650,9 +732,16 @@ __global__ __launch_bounds__(256) void pw_split_reduce(PwArgs a, long quads) {
 
 template <typename T> void launch_pw(const PwArgs& a, int N, int cfg, hipStream_t s) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
-    if (cfg >= 7) {                                                  // LDS-tiled form (a.nsplit, a.part set by the host for split-K)
-        const int ns = a.nsplit > 1 ? a.nsplit : 1;
-        hipLaunchKernelGGL((pw_gemm_lds<T>), dim3(cdiv(a.MT, 4), cdiv(a.NT, 4), N * ns), dim3(256), pwl_lds_bytes<T>(), s, a);
+    if constexpr (sizeof(T) == 2) { if (cfg >= 7) cfg = 0; }         // the pipelined form exists for fp32-stored activations only
+    if constexpr (sizeof(T) == 4) if (cfg >= 7) {                    // LDS-tiled pipelined form (a.nsplit, a.part set by the host for split-K)
+        PwArgs b = a;
+        const int ns = a.nsplit > 1 ? a.nsplit : 1, mw = cfg >= 11 ? 2 : 1;                     // 11..13: 128-pixel tiles
+        const int tiles = cdiv(a.MT, 4 * mw) * cdiv(a.NT, 4) * ns * N;
+        b.nsamp = N;
+        b.w_major = (double)a.NT * 16 >= (double)a.HW * N;           // weights the larger operand (per K element)
+        const dim3 grid(8 * cdiv(tiles, 8));
+        if (mw == 2) hipLaunchKernelGGL((pw_gemm_lds<T, 2>), grid, dim3(PWL_NTH), pwl_lds_bytes<2>(), s, b);
+        else hipLaunchKernelGGL((pw_gemm_lds<T, 1>), grid, dim3(PWL_NTH), pwl_lds_bytes<1>(), s, b);
         if (a.part) {
             const long quads = (long)N * a.HW * (a.Cout / 4);
             hipLaunchKernelGGL((pw_split_reduce<T>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
@@ -2952,6 +3041,10 @@ template <typename T> static void conv_attr_all() {
 }
 void kernels_init() {
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
+    (void)hipFuncSetAttribute((const void*)pw_gemm_lds<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)pw_gemm_lds<f32s, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)pw_gemm_lds<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<2>());
+    (void)hipFuncSetAttribute((const void*)pw_gemm_lds<f32s, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<2>());
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<f16, f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f16>());
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, f32s>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f32s>());
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<float>());

@@ -183,11 +183,13 @@ def test_column_tiled_depthwise_forced_on_a_small_frame(gc, monkeypatch):
     assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
 
 
-@pytest.mark.parametrize("cfg", ["7", "9"])
+@pytest.mark.parametrize("cfg", ["7", "9", "11", "12"])
 def test_lds_tiled_pointwise_gemm_forced(gc, monkeypatch, cfg):
-    """pw_gemm_lds (64 x 64 tiles through LDS, weight fragments by LDS-DMA; cfg 9: split-K in four slices + reduce pass) is
-    normally one of the candidates plan-time measurement chooses from; forced here on every 1x1 layer that admits it, both
-    variants (resnet50: strided 1x1, residual + ReLU after the add, pooled sums for the LR-ASPP gate)."""
+    """pw_gemm_lds (64- or 128-pixel x 64-channel tiles, both operands by LDS-DMA through a six-stage ring; cfg 9 / 12:
+    split-K in four / two slices + reduce pass) is normally one of the candidates plan-time measurement chooses from; forced
+    here on every 1x1 layer that admits it, both variants (resnet50: strided 1x1, residual + ReLU after the add, pooled
+    sums for the LR-ASPP gate; mobilenetv3: channel counts that are no multiple of 32, i.e. a masked last K step).  The
+    fp16-storage mode has no such kernel (the hook then selects configuration 0)."""
     monkeypatch.setenv("RVM_PW_CFG", cfg)
     monkeypatch.setenv("RVM_AUTOTUNE", "0")
     w = gc.run("fp32", H=122, W=218, ds=0.5, T=2, B=2, variant="resnet50", verbose=False)
