@@ -209,6 +209,7 @@ struct rvm_ctx {
     int enc_out = 0, aspp_c = 0, feat[4], dec[4];
     GruLayer gru[4];            // decode4, decode3, decode2, decode1
     Conv3Layer up[3];           // decode3, decode2, decode1
+    Conv3Layer up_ch[3];        // the same weights packed in 56-channel chunks where up[i] is not (KS == 0: none): tall tiles for batched frames
     Conv3Layer out0, out1;      // decode0 conv.0, conv.3
     size_t dgf = 0, dgf_mlp = 0;
 
@@ -409,7 +410,8 @@ size_t conv_lds(const rvm_ctx* c, int MW, int geo, int CC) {
     return c->dtype == RVM_DTYPE_F16 ? conv_lds_bytes<f16>(MW, 2, KD, S, D, CC, SK) : conv_lds_bytes<float>(MW, 2, KD, S, D, CC, SK);   // f32s == float
 }
 bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout, const std::vector<int>& out_map,
-                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0, bool splittable = false) {
+                const std::vector<int>& srcC, const std::vector<int>& srcOrig, Conv3Layer& L, int geo = 0, bool splittable = false,
+                bool force_chunks = false) {
     auto W = c->P(wname);
     if (!W) { g_err = "missing parameter " + wname; return false; }
     int tot = 0, cin = 0;
@@ -424,7 +426,7 @@ bool pack_conv3(rvm_ctx* c, const std::string& wname, const Affine& af, int Cout
     L.Cpad = (int)in_map.size(); L.Cout = Cout; L.Cin = cin; L.geo = geo; L.KD = geo == 3 ? 7 : 3;
     // one pass if the whole-channel halo patch fits comfortably, else channel chunks of <= 64 KiB
     L.CC = L.Cpad; L.nchunks = 1;
-    if (splittable && geo != 3 && L.Cpad >= 224) {
+    if (splittable && geo != 3 && (L.Cpad >= 224 || force_chunks)) {
         // long-K layers with a plain bias + ReLU epilogue (resnet50 bottleneck 3x3s, the decoder's cat convs): chunks of
         // 56 channels (9 * 56 / 32 = 15.75 -> 16 K steps, no padding to speak of) that conv_kxk's split mode runs side by
         // side on different CUs; 56 channels keep a 20-row tile's halo patch inside LDS
@@ -576,6 +578,10 @@ int finalize_impl(rvm_ctx* c) {
         // sources: up(a) | up(h) | f | s(NHWC4)   == reference cat[x, f, s] with x = cat[a, h]
         if (!pack_conv3(c, p + ".conv.0.weight", af, uout[i], iota_map(uout[i], rup(uout[i], 16)),
                         {uin[i] / 2, uin[i] / 2, usk[i], 4}, {uin[i] / 2, uin[i] / 2, usk[i], 3}, c->up[i], 0, true)) return 1;
+        c->up_ch[i] = Conv3Layer();
+        if (c->up[i].nchunks == 1 && c->up[i].Cpad >= 96 &&
+            !pack_conv3(c, p + ".conv.0.weight", af, uout[i], iota_map(uout[i], rup(uout[i], 16)),
+                        {uin[i] / 2, uin[i] / 2, usk[i], 4}, {uin[i] / 2, uin[i] / 2, usk[i], 3}, c->up_ch[i], 0, true, true)) return 1;
         if (!pack_gru(c, p + ".gru", uout[i] / 2, c->gru[i + 1])) return 1;
     }
     if (!bn_fold(c, "decoder.decode0.conv.1", dec[3], 1e-5f, af)) return 1;
@@ -828,9 +834,38 @@ int build_plan(rvm_ctx* c) {
 
     // KxK conv launcher: (Ho, Wo) output, (Hi, Wi) input of the direct sources
     // (`keep`: hand the launch back instead of adding it to the frame - the caller schedules it itself)
-    auto conv3 = [&](const std::string& name, const Conv3Layer& L, int Ho, int Wo, int Hi, int Wi, int epi,
+    auto conv3 = [&](const std::string& name, const Conv3Layer& L0, int Ho, int Wo, int Hi, int Wi, int epi,
                      std::function<void(ConvArgs&, const FrameIO&)> fill, int nb = 0,
-                     std::function<void(hipStream_t, const FrameIO&)>* keep = nullptr) -> int {
+                     std::function<void(hipStream_t, const FrameIO&)>* keep = nullptr, const Conv3Layer* alt = nullptr) -> int {
+        // `alt`: the same layer packed in 56-channel chunks.  Its halo patch holds one chunk at a time, so 20-row tiles
+        // fit LDS where the unchunked patch allows 4 or 8 rows: with many frames per launch the weight stream per output
+        // pixel is what the launch costs.  Offered as extra candidates when several frames are planned (measured then).
+        const bool alt_ok = alt && alt->KS > 0 && alt->nchunks > 1 && alt->CC == 56 && (nb ? nb : Bs * TT) > 1 && L0.geo == 0 && L0.nchunks == 1;
+        int alt_first = -1, alt_force = -1;                 // index of the first alt candidate among the valid ones
+        static const int alt_cand[4][2] = {{5, 2}, {5, 1}, {2, 2}, {5, 4}};
+        constexpr int NALT = 4;
+        const Conv3Layer* Lp = &L0;
+        {
+            // the candidate list is rebuilt the same way on every build_plan pass, so the tuned index decides here already
+            // which packing the rest of this function sees
+            if (alt_ok) {
+                const int cand[6][2] = {{4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}, {0, epi == EPI_GRU_IH ? 2 : 1}};
+                int nvalid = 0;
+                for (int k = 0; k < 5; ++k) {                  // (conv_sk never applies: these layers have upsampled sources)
+                    if (epi == EPI_GRU_IH && cand[k][1] != 2) continue;
+                    if (conv_lds_bytes<T>(cand[k][0], cand[k][1], 3, 1, 1, L0.CC, 4) > 150 * 1024) continue;
+                    ++nvalid;
+                }
+                alt_first = nvalid;
+                auto it = c->tuned.find(tune_key(name));
+                if (it != c->tuned.end() && it->second >= alt_first && it->second < alt_first + NALT) Lp = alt;
+                if (const char* e = getenv("RVM_CONV_ALT")) {           // test hook: force chunked candidate 0..3
+                    alt_force = atoi(e);
+                    if (alt_force >= 0 && alt_force < NALT) Lp = alt; else alt_force = -1;
+                }
+            }
+        }
+        const Conv3Layer& L = *Lp;
         const int B = nb ? nb : Bs * TT;                    // samples of this launch (a GRU step: Bs)
         ConvArgs a; memset(&a, 0, sizeof a);
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
@@ -878,8 +913,16 @@ int build_plan(rvm_ctx* c) {
                 valid[nvalid++] = k;
             }
             if (nvalid == 0) return fail("conv: input patch does not fit LDS");
-            const int pick = valid[tune_pick(name, nvalid, model)];
+            if (alt_ok && nvalid != alt_first) return fail("conv: candidate lists of the two packings disagree");
+            const int pick = valid[tune_pick(name, nvalid + (alt_ok ? NALT : 0), model)];      // (an alt index never reaches here: Lp == alt then)
             MW = cand[pick][0]; NW = cand[pick][1];
+        } else if (Lp == alt && alt_ok) {
+            // the chunked packing, one block per tile looping over the chunks
+            int k = tune_pick(name, alt_first + NALT, 0) - alt_first;
+            if (alt_force >= 0) k = alt_force;
+            if (k < 0 || k >= NALT) k = 0;
+            MW = alt_cand[k][0]; NW = alt_cand[k][1];
+            if (NW > L.NT) NW = L.NT >= 2 ? 2 : 1;
         } else if (L.nchunks > 1 && L.KD == 3 && epi == EPI_RELU && L.CC == 56) {
             // Long-K layer packed in 56-channel chunks: conv_kxk's split mode (the chunks side by side on different CUs,
             // partial sums added by a second pass) in several tile shapes, the one-block-per-tile chunk loop, and conv_sk.
@@ -1255,7 +1298,7 @@ int build_plan(rvm_ctx* c) {
                 a.src[2] = ConvSrc{sk, skC, skC, 0, 0, 0, 0};
                 a.src[3] = ConvSrc{sl, 4, 4, 0, 0, 0, 0};
                 a.nsrc = 4; a.y = X; a.ys = Cout;
-            })) return 1;
+            }, 0, nullptr, &c->up_ch[i])) return 1;
         if (gru("decode" + std::to_string(l) + ".gru", c->gru[i + 1], X + Cout / 2, Cout, lh[l], lw[l], hidx - 1)) return 1;
         c->taps["x" + std::to_string(l)] = Tap{X, B, lh[l], lw[l], Cout, Cout, false};
         xa = X; xaC = Cout / 2; xaS = Cout;

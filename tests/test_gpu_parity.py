@@ -201,6 +201,20 @@ def test_lds_tiled_pointwise_gemm_forced(gc, monkeypatch, cfg):
     assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
 
 
+@pytest.mark.parametrize("k", ["0", "1", "2", "3"])
+def test_chunked_decoder_convs_forced(gc, monkeypatch, k):
+    """decode3.conv / decode2.conv in their second packing (56-channel chunks, one block per 20- or 8-row tile looping over
+    the chunks, x2-upsampled sources staged chunk by chunk): normally a plan-time candidate for batched frames only; forced
+    here (B = 2 and a chunk of T = 2) against the oracle, all taps."""
+    monkeypatch.setenv("RVM_CONV_ALT", k)
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+    w = gc.run("fp32", H=150, W=201, ds=0.8, T=2, B=2, verbose=False)
+    for key, v in w.items():
+        assert v < TOL32, (key, v, w)
+    w = gc.run("fp16", H=540, W=960, ds=0.5, T=2, B=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+
+
 def test_fp32_1080p_at_ratio_one():
     """1920x1080 at downsample_ratio=1: the low-res map is the full frame, wider than any full-width LDS tile of the
     depthwise kernel (column tiles) - the largest shape the reference runs on common inputs."""
