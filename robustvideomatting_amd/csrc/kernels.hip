@@ -2330,24 +2330,34 @@ __device__ __forceinline__ f32x4 mma_hl(f32x4 acc, const f16* wfrag, int lane, c
 // and weight fragments as conv_kxk: K index = tap * 16 + channel, 5 K steps, one n-tile; 21 m-tiles of 16 pixels over
 // the 4 waves), keeps it in LDS for the projection / the MLP and writes the interior to memory (segmentation pass,
 // debug taps).  One launch and one trip of `hid` through memory less.  TC = arithmetic type of the conv.
-constexpr int DGF_HS = 20;                                              // floats per pixel of the hid tile in LDS (16 + pad)
+// LDS of a block, kept under a third of the CU's 160 KB (three blocks per CU: the 510 blocks of an HD / 4K frame then
+// start at once with room to spare - at two per CU a few of them waited for a second round, and a batched launch runs three
+// rows of blocks per CU instead of two):
+//   [0, PATCHB)  the 20 x 20 patch of the first conv's output; once the conv is done, the MLP weight fragments
+//                (9 x 1024 f16 = 18 KB) and the guided filter's inputs sx, sy (2 x 324 x 16 B) move into the same bytes
+//   hid tile     [18 * 18][16] fp32 without padding; the four 16-byte pieces of a pixel are XOR-swizzled by (pixel >> 2) & 3
+//                so that 16 consecutive pixels reading the SAME piece hit 16 different bank sets
+//   project_mat  weights [4][16] + bias [4]
+constexpr int DGF_HS = 16;                                              // floats per pixel of the hid tile in LDS
+__device__ __forceinline__ int dgf_hsw(int pp, int piece) { return pp * DGF_HS + ((piece ^ ((pp >> 2) & 3)) << 2); }
 template <typename TC> constexpr int dgf_patch_csl() { return 16 + Tr<TC>::kLdsPad; }
-template <typename TC> constexpr size_t dgf_lds_bytes() {
+template <typename TC> constexpr size_t dgf_patch_bytes() {
     size_t patch = (size_t)20 * 20 * dgf_patch_csl<TC>() * sizeof(TC);
-    if (patch < 9 * 1024 * 2) patch = 9 * 1024 * 2;                      // the MLP weight fragments move in once the patch is dead
-    return patch + (size_t)18 * 18 * DGF_HS * 4 + (size_t)2 * 18 * 18 * 16 + 68 * 4 + 16;
+    const size_t later = (size_t)9 * 1024 * 2 + (size_t)2 * 18 * 18 * 16;   // what moves in once the patch is dead
+    return patch < later ? later : patch;
 }
+template <typename TC> constexpr size_t dgf_lds_bytes() { return dgf_patch_bytes<TC>() + (size_t)18 * 18 * DGF_HS * 4 + 68 * 4 + 16; }
 template <typename T, typename TC>
 __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int CSL = dgf_patch_csl<TC>();
-    constexpr size_t PATCHB = dgf_lds_bytes<TC>() - (size_t)18 * 18 * DGF_HS * 4 - (size_t)2 * 18 * 18 * 16 - 68 * 4 - 16;
-    TC* patch = (TC*)dsm;                                               // [20 * 20][CSL], later wl
+    constexpr size_t PATCHB = dgf_patch_bytes<TC>();
+    TC* patch = (TC*)dsm;                                               // [20 * 20][CSL], later wl | sx | sy
     f16* wl = (f16*)dsm;                                                // W1[t] x4, W2, W3[t] x4 (9 x 1024 f16)
-    float* hidt = (float*)(dsm + PATCHB);                               // [18 * 18][DGF_HS]
-    f32x4* sx = (f32x4*)(hidt + 18 * 18 * DGF_HS);
+    f32x4* sx = (f32x4*)(dsm + 9 * 1024 * 2);
     f32x4* sy = sx + 18 * 18;
+    float* hidt = (float*)(dsm + PATCHB);                               // [18 * 18][DGF_HS], pieces swizzled (dgf_hsw)
     const DgfWeights& wt = *a.wt;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
@@ -2374,7 +2384,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         inb[r] = gy >= 0 && gy < a.h && gxx >= 0 && gxx < a.w;
         xr[r] = ld4f(s0 + (inb[r] ? (size_t)gy * a.w + gxx : 0) * 4);
     }
-    float* pjl = (float*)(sy + 18 * 18);                                // project_mat weights [4][16] + bias [4], via LDS
+    float* pjl = hidt + 18 * 18 * DGF_HS;                               // project_mat weights [4][16] + bias [4], via LDS
     const float pjv = ((const float*)&wt.proj_w[0][0])[min(tid, 67)];   // proj_w and proj_b are adjacent in DgfWeights
     {
         const ConvSrc S = ConvSrc{a.hin, 16, 16, 0, 0, 0, 0, 0, 0};
@@ -2418,7 +2428,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (float)(T)fmaxf(v[r], 0.f);       // as it would come back from memory
             hv_[rd][u] = v;
-            if ((mt0 + 4 * u) * 16 + lx < 324) *(f32x4*)(hidt + pp[u] * DGF_HS + g * 4) = v;
+            if ((mt0 + 4 * u) * 16 + lx < 324) *(f32x4*)(hidt + dgf_hsw(pp[u], g)) = v;
         }
     }
     stamp(2);
@@ -2449,7 +2459,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
                     float hv[16];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const f32x4 t = *(const f32x4*)(hidt + pp * DGF_HS + 4 * k);
+                        const f32x4 t = *(const f32x4*)(hidt + dgf_hsw(pp, k));
                         hv[4 * k] = t[0]; hv[4 * k + 1] = t[1]; hv[4 * k + 2] = t[2]; hv[4 * k + 3] = t[3];
                     }
 #pragma unroll
@@ -2471,8 +2481,8 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
             const int rg = (g - t) & 3;
             const int gyt = y0 + 4 * wave + t;
             const bool ok = (rg == 1 || rg == 2) && gyt < a.h && gx < a.w;
-            const float* hp = hidt + ((4 * wave + t + 1) * 18 + lx + 1) * DGF_HS + (ok ? (rg - 1) * 8 : 0);
-            const f32x4 h0 = *(const f32x4*)hp, h1 = *(const f32x4*)(hp + 4);
+            const int hpp = (4 * wave + t + 1) * 18 + lx + 1, hpc = ok ? (rg - 1) * 2 : 0;
+            const f32x4 h0 = *(const f32x4*)(hidt + dgf_hsw(hpp, hpc)), h1 = *(const f32x4*)(hidt + dgf_hsw(hpp, hpc + 1));
             hs[t][0] = ok ? h0 : f32x4{0, 0, 0, 0};
             hs[t][1] = ok ? h1 : f32x4{0, 0, 0, 0};
         }
