@@ -42,6 +42,8 @@ HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
 MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 2.5e15, "bf16": 2.5e15, "fp32": 157.3e12}   # dense peak of the MFMA the mode issues (f16 / f16 split / f32)
 PMC_FILES = {"hd": "profiles/r02/pmc_hd.json", "4k": "profiles/r02/pmc_4k.json",
              "hd_resnet50": "profiles/r02/pmc_rn.json"}              # tools/run_pmc.sh output of this command
+TRACE_FILES = {"hd": "profiles/r02/hd_kernel_trace_table.txt", "4k": "profiles/r02/4k_kernel_trace_table.txt",
+               "hd_resnet50": "profiles/r02/rn_kernel_trace_table.txt"}     # tools/run_prof.sh output of this command
 TORCH_DTYPE = {"fp32": torch.float32, "fp16": torch.float16, "fp16fast": torch.float16, "bf16": torch.bfloat16}
 
 
@@ -186,6 +188,18 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
             if e["name"] == name:
                 roof["traffic"] = e["fetch_bytes"] + e["write_bytes"]
                 roof["traffic_source"] = PMC_FILES[wl_key] + " (" + e.get("fetch_note", "raw FETCH_SIZE") + ")"
+    # ... and the committed rocprofv3 --kernel-trace mean duration of the same launch: the hipEvent figure above carries the
+    # spacing of two event records (~2-3 us more than the kernel's own begin-to-end time), so both are shown
+    trace = os.path.join(ROOT, TRACE_FILES.get(wl_key, ""))
+    if batch == 1 and chunk == 1 and a.dtype == "fp16" and os.path.isfile(trace):
+        import re
+        for line in open(trace):
+            m = re.match(r"\s+(\S+)\s+([\d.]+) us", line)
+            if m and m.group(1) == name:
+                roof["rocprof_kernel_ms"] = float(m.group(2)) * 1e-3
+                roof["rocprof_frac"] = (flops if roof["bound"] == "mfma" else nbytes) / (float(m.group(2)) * 1e-6) / \
+                    (MFMA_PEAK[a.dtype] if roof["bound"] == "mfma" else HBM_PEAK)
+                roof["rocprof_source"] = TRACE_FILES[wl_key]
     if dump:
         os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
         with open(dump, "w") as f:
