@@ -1998,6 +1998,20 @@ __device__ __forceinline__ void state_prep(const StatePrep& sp, int blk, int tid
     }
     *(f32x4*)(out + i) = v;
 }
+// two neighbouring elements of a source row, loaded as one (element-aligned) access
+template <typename TIO> struct TIO2 { float a, b; };
+typedef unsigned int u32_a2 __attribute__((aligned(2)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ TIO2<f16> ld_pair(const f16* p) {
+    const unsigned u = *(const u32_a2*)p;
+    return TIO2<f16>{(float)__builtin_bit_cast(f16, (unsigned short)(u & 0xFFFFu)), (float)__builtin_bit_cast(f16, (unsigned short)(u >> 16))};
+}
+__device__ __forceinline__ TIO2<bf16> ld_pair(const bf16* p) {
+    const unsigned u = *(const u32_a2*)p;
+    return TIO2<bf16>{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+}
+__device__ __forceinline__ TIO2<float> ld_pair(const float* p) { const f32x2_a4 v = *(const f32x2_a4*)p; return TIO2<float>{v[0], v[1]}; }
+
 template <typename T, typename TIO, bool STEM>
 __global__ __launch_bounds__(256) void downsample(DownArgs a) {
     [[maybe_unused]] Stamper stamp;
@@ -2039,11 +2053,23 @@ __global__ __launch_bounds__(256) void downsample(DownArgs a) {
         const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
         const float ly = sy - y0, lx = sx - x0;
         f32x4 r;
+        // the two taps of a row are neighbours (x1 = x0 + 1, or x1 = x0 on the last column): one load of the pair
+        // [xb, xb + 1], xb = min(x0, W - 2) - a 4-byte load at a 2-byte aligned address for the 16-bit types - instead of
+        // two element loads: 6 instead of 12 vector-memory instructions per pixel
+        const int xb = min(x0, a.W - 2);
+        const bool first_hi = x0 != xb, second_lo = x1 == xb;      // (x0 == W - 1: both taps are the pair's second element)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const TIO* pl = sp + c * plane;
-            const float v00 = (float)pl[(size_t)y0 * a.W + x0], v01 = (float)pl[(size_t)y0 * a.W + x1];
-            const float v10 = (float)pl[(size_t)y1 * a.W + x0], v11 = (float)pl[(size_t)y1 * a.W + x1];
+            float v00, v01, v10, v11;
+            if (a.W >= 2) {                                          // uniform
+                const TIO2<TIO> p0 = ld_pair(pl + (size_t)y0 * a.W + xb), p1 = ld_pair(pl + (size_t)y1 * a.W + xb);
+                v00 = first_hi ? p0.b : p0.a; v01 = second_lo ? p0.a : p0.b;
+                v10 = first_hi ? p1.b : p1.a; v11 = second_lo ? p1.a : p1.b;
+            } else {
+                v00 = (float)pl[(size_t)y0 * a.W + x0]; v01 = (float)pl[(size_t)y0 * a.W + x1];
+                v10 = (float)pl[(size_t)y1 * a.W + x0]; v11 = (float)pl[(size_t)y1 * a.W + x1];
+            }
             r[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
             r[c] = (float)(T)r[c];
         }
