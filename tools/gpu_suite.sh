@@ -1,4 +1,4 @@
-# round 2, first GPU pass: full GPU suite, the no-alloc entry point's test, default bench
+# Full GPU pass (GPU box): every -m gpu test, the allocation-free entry point's test alone in a fresh process, the default bench line.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -v --timeout 300 --timeout-method thread > gpurun_out/r2_pytest.txt 2>&1 || { tail -40 gpurun_out/r2_pytest.txt; exit 1; }
 tail -5 gpurun_out/r2_pytest.txt
