@@ -23,4 +23,4 @@ with open('gpurun_out/mb_table.txt', 'w') as o:
         o.write('%-30s blocks %5d x %4d  dur %6.2f us  gap %5.2f us\n' % (k[0], k[1], k[2], a[0]/a[2]/1e3, a[1]/a[2]/1e3))
 PY
 rm -rf gpurun_out/mb
-# build:  for f in floor floor2 cufetch atomics; do hipcc -O3 --offload-arch=gfx950 -o tools/microbench/$f tools/microbench/$f.hip; done
+# build:  for f in floor floor2 cufetch atomics gridbar; do hipcc -O3 --offload-arch=gfx950 -o tools/microbench/$f tools/microbench/$f.hip; done
