@@ -530,6 +530,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_
 __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {           // result valid after lds_wait() on it
     f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v;
 }
+template <int OFF> __device__ __forceinline__ f32x4 lds_read16_at(unsigned addr) {   // the same with an immediate byte offset
+    f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v;
+}
 __device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
@@ -632,21 +635,27 @@ __global__ __launch_bounds__(PWL_NTH) void pw_gemm_lds(PwArgs a) {
         if (ks + NS - 1 < ks_hi) issue(ks + NS - 1, st == 0 ? NS - 1 : st - 1);
         const unsigned so = st * STAGE;
         f32x4 wr[2][2], xr[MW][2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) { wr[ni][0] = lds_read16(woff[ni] + so); wr[ni][1] = lds_read16(woff[ni] + so + 1024); }
+        const unsigned wa = woff[0] + so;                            // the wave's two weight fragments are 2048 bytes apart
+        wr[0][0] = lds_read16_at<0>(wa); wr[0][1] = lds_read16_at<1024>(wa);
+        wr[1][0] = lds_read16_at<2048>(wa); wr[1][1] = lds_read16_at<3072>(wa);
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) { xr[mi][0] = lds_read16(aoff[mi][0] + so); xr[mi][1] = lds_read16(aoff[mi][1] + so); }
         if (ks > ks_lo) mma_tile(acc, wo, xo);
         lds_wait(wr[0][0], wr[0][1], wr[1][0], wr[1][1]);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) pwl_frag(wi[ni], wr[ni][0], wr[ni][1]);
-        const bool tail = ks * 32 + 32 > a.Cin && ks * 32 + g * 8 >= a.Cin;     // the last, partial K step: lanes past Cin hold whatever was there
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             lds_wait(xr[mi][0], xr[mi][1]);
             XRaw<T> x; x.a = xr[mi][0]; x.b = xr[mi][1];
             xi[mi] = x.frag();
-            if (tail) xi[mi].zero();
+        }
+        if (ks * 32 + 32 > a.Cin) {                                  // the last, partial K step (uniform branch, kept a branch by the asm):
+            asm volatile("; partial K step" ::: "memory");           // lanes past Cin hold whatever was there
+            if (ks * 32 + g * 8 >= a.Cin) {
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi) xi[mi].zero();
+            }
         }
         st = st + 1 == NS ? 0 : st + 1;
     };
