@@ -40,10 +40,11 @@ WORKLOADS = {
 }
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
 MFMA_PEAK = {"fp16fast": 2.5e15, "fp16": 2.5e15, "bf16": 2.5e15, "fp32": 157.3e12}   # dense peak of the MFMA the mode issues (f16 / f16 split / f32)
-PMC_FILES = {"hd": "profiles/r02/pmc_hd.json", "4k": "profiles/r02/pmc_4k.json",
-             "hd_resnet50": "profiles/r02/pmc_rn.json"}              # tools/run_pmc.sh output of this command
-TRACE_FILES = {"hd": "profiles/r02/hd_kernel_trace_table.txt", "4k": "profiles/r02/4k_kernel_trace_table.txt",
-               "hd_resnet50": "profiles/r02/rn_kernel_trace_table.txt"}     # tools/run_prof.sh output of this command
+PROFILE_DIR = "profiles/r03"
+# committed rocprofv3 evidence of the same command, keyed by (workload, streams per GPU, chunk): tools/run_pmc.sh (--pmc passes)
+# and tools/run_prof.sh (--kernel-trace --stats)
+PROFILE_TAGS = {("hd", 1, 1): "hd", ("4k", 1, 1): "4k", ("hd_resnet50", 1, 1): "rn", ("hd", 8, 1): "hd_b8", ("hd", 1, 12): "hd_c12"}
+L3_BYTES = 256 << 20         # Infinity Cache (MI355X_MICROARCH.md): the src ring is sized past it
 TORCH_DTYPE = {"fp32": torch.float32, "fp16": torch.float16, "fp16fast": torch.float16, "bf16": torch.bfloat16}
 
 
@@ -88,38 +89,90 @@ def cpu_baseline(wl, seconds=15.0, T=2):
 
 
 def spawn_ranks(a):
-    """`python bench.py --gpus N` with no launcher: N children, one per GPU; this process never touches the GPU."""
+    """`python bench.py --gpus N` with no launcher: N fresh children, one per GPU; this process never touches the GPU.
+    All children are polled: when one exits non-zero the others are terminated (a rank that died at start-up would leave
+    the rest in the barrier until the caller's time limit) and the exit code is non-zero.  Every rank's stderr is kept
+    and replayed on failure; rank 0's stdout is the result line."""
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, WORLD_SIZE=str(a.gpus), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        ef = tempfile.TemporaryFile()
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    rc, failed = 0, None
+    live = set(range(a.gpus))
+    while live and failed is None:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc, failed = code, r
+                break
+        else:
+            if live:
+                time.sleep(0.05)
+    if failed is not None:
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    out = procs[0].stdout.read() if procs[0].stdout else b""
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were terminated\n" % (failed, rc))
+        for r, ef in enumerate(errs):
+            ef.seek(0)
+            tail = ef.read().decode(errors="replace")[-4000:]
+            if tail.strip():
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, tail))
+    else:
+        errs[0].seek(0)
+        sys.stderr.write(errs[0].read().decode(errors="replace"))
     sys.stdout.write(out.decode())
     sys.stdout.flush()
-    return rc
+    return rc if rc else 0
+
+
+def _ring_frames(H, W, batch, chunk, es, ring):
+    """How many distinct step inputs the src ring holds: enough that their total exceeds the 256 MiB Infinity Cache, so a
+    frame is not served from cache when its turn comes again (a real stream brings a new frame every step)."""
+    if ring > 0:
+        return ring
+    per_step = 3 * H * W * es * batch * chunk
+    return max(2, -(-int(L3_BYTES * 1.1) // per_step))
 
 
 def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump=""):
     """Time `steps` steps of one workload on this rank; rank 0 also gets the live per-launch roofline."""
     wl = WORKLOADS[wl_key]
     tdt = TORCH_DTYPE[a.dtype]
+    es = 4 if a.dtype == "fp32" else 2
     variant = wl.get("variant", "mobilenetv3")
     model = MattingNetwork(variant, "deep_guided_filter").eval()
     model.load_state_dict(synthetic.make_params(variant, "deep_guided_filter", seed=0))
     model = model.to(dev, tdt)
     model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")
-    clip = synthetic.make_clip(chunk, wl["H"], wl["W"], seed=rank, B=batch).to(dev, tdt).contiguous()
-    src = clip[:, 0].contiguous() if chunk == 1 else clip
+    # the ring of step inputs: n_ring distinct frames (batches / chunks) of one synthetic clip per stream
+    n_ring = _ring_frames(wl["H"], wl["W"], batch, chunk, es, a.src_ring)
+    ring = []
+    gen = [synthetic.clip_frames(n_ring * chunk, wl["H"], wl["W"], seed=rank * 64 + b) for b in range(batch)]
+    for _ in range(n_ring):
+        fr = torch.stack([torch.stack([next(g) for _ in range(chunk)]) for g in gen])      # [B, chunk, 3, H, W]
+        fr = fr.to(dev, tdt)
+        ring.append(fr[:, 0].contiguous() if chunk == 1 else fr.contiguous())
+    del gen
     ds = wl["ds"]
 
     def sync_all():
@@ -131,19 +184,48 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     # rank r owns streams {r, r+world, ...} of the world*batch streams; they advance together as one batch
     ids = streams.shard_streams(world * batch, world, rank)
     runner = streams.StreamRunner(model, ids, ds)
+
+    def timed(n_steps, inputs, sync_each=False, collective=True):
+        k = len(inputs)
+        with torch.no_grad():
+            if collective:
+                sync_all()
+            else:
+                torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                o = runner.step(inputs[i % k])
+                if sync_each:
+                    torch.cuda.synchronize(dev)
+            if collective:
+                sync_all()
+            else:
+                torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0, o
+
     with torch.no_grad():
-        for _ in range(warmup):
-            out = runner.step(src)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = runner.step(src)
-        sync_all()
-        dt_local = time.perf_counter() - t0
+        for i in range(warmup):
+            out = runner.step(ring[i % n_ring])
+    dt_local, out = timed(steps, ring)
     on_gloo = dist is not None and dist.get_backend() == "gloo"
     fps, frames, dt = streams.aggregate_throughput(steps * batch * chunk, dt_local, dist, None if on_gloo else dev)
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
-    res = dict(fps=fps, ms_per_step=dt / steps * 1e3, steps=steps, workload=wl["name"], streams_per_gpu=batch, chunk=chunk)
+    res = dict(fps=fps, ms_per_step=dt / steps * 1e3, steps=steps, workload=wl["name"], streams_per_gpu=batch, chunk=chunk,
+               src_ring=n_ring, fps_local=steps * batch * chunk / dt_local)
+    if dist is not None:                                    # every rank's own rate, for rank 0's line
+        import torch as _t
+        mine = _t.tensor([res["fps_local"]], dtype=_t.float64, device=None if on_gloo else dev)
+        allr = [_t.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        res["fps_per_rank"] = [float(t.item()) for t in allr]
+    # the other two protocols, untimed for the headline: the same input every step (what round 1 / 2 measured: the frame
+    # then sits in the Infinity Cache) and the reference's loop, which synchronises after every frame
+    # (inference_speed_test.py:45-47)
+    n2 = max(20, min(steps, 100))
+    dt1, _ = timed(n2, ring[:1], collective=False)
+    dt2, _ = timed(n2, ring, sync_each=True, collective=False)
+    res["fps_single_src"] = n2 * batch * chunk / dt1
+    res["fps_sync_every_frame"] = n2 * batch * chunk / dt2
     if rank != 0:
         return res
     # ---- live per-kernel timing (hipEvents on the stream the kernels are launched on)
@@ -155,43 +237,57 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     rb = [torch.zeros(s, device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last) for s in shapes]
     fgr = torch.empty((batch * chunk, 3, wl["H"], wl["W"]), device=dev, dtype=tdt)
     pha = torch.empty((batch * chunk, 1, wl["H"], wl["W"]), device=dev, dtype=tdt)
-    if chunk > 1:
-        src = clip.transpose(0, 1).contiguous()             # the native call takes time-major frames
-    samples = []
+    native_src = [r if chunk == 1 else r.transpose(0, 1).contiguous() for r in ring]      # the native call takes time-major frames
     reps = 21
-    for i in range(reps + 3):
-        ms = ctx.profile_frame(src.data_ptr(), [t.data_ptr() for t in ra], fgr.data_ptr(), pha.data_ptr(),
-                               [t.data_ptr() for t in rb], stream)
-        ra, rb = rb, ra
-        if i >= 3:
-            samples.append(ms)
-    avg = [sorted(col)[reps // 2] for col in zip(*samples)]      # median per launch: one stalled frame must not name the kernel
+
+    def profile(inputs):
+        nonlocal ra, rb
+        samples = []
+        for i in range(reps + 3):
+            x = inputs[i % len(inputs)]
+            ms = ctx.profile_frame(x.data_ptr(), [t.data_ptr() for t in ra], fgr.data_ptr(), pha.data_ptr(),
+                                   [t.data_ptr() for t in rb], stream)
+            ra, rb = rb, ra
+            if i >= 3:
+                samples.append(ms)
+        return [sorted(col)[reps // 2] for col in zip(*samples)]      # median per launch: one stalled frame must not name the kernel
+
+    avg = profile(native_src)
+    avg_single = profile(native_src[:1])
     k = max(range(len(info)), key=lambda i: avg[i])
     name, flops, nbytes = info[k]
     sec = avg[k] * 1e-3
     intensity = flops / max(nbytes, 1.0)
     ridge = MFMA_PEAK[a.dtype] / HBM_PEAK
-    is_gemm = any(s in name for s in (".expand", ".project", "1x1", ".conv", ".gru"))
+    is_gemm = any(s in name for s in (".expand", ".project", "1x1", ".conv", ".gru", ".fused"))
     if is_gemm and intensity > ridge:
         roof = dict(bound="mfma", achieved=flops / sec / 1e12, peak=MFMA_PEAK[a.dtype] / 1e12, unit="TFLOP/s",
                     frac=flops / sec / MFMA_PEAK[a.dtype], traffic=None)
     else:
         roof = dict(bound="hbm", achieved=nbytes / sec / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=nbytes / sec / HBM_PEAK, traffic=None)
-    roof.update(kernel=name, kernel_ms=avg[k], kernel_flops=flops, kernel_bytes=nbytes,
+    roof.update(kernel=name, kernel_ms=avg[k], kernel_ms_single_src=avg_single[k], kernel_flops=flops, kernel_bytes=nbytes,
                 sum_kernel_ms=sum(avg), launches=len(info), kernels=sum(ctx.launch_kernels()))
+    # the full-resolution refiner pass (the one HBM-bound launch of the frame) with the input rotating through the ring
+    # and with one input re-used (then src comes out of the Infinity Cache)
+    for i, (nm, fl, by) in enumerate(info):
+        if nm == "dgf_apply_fullres":
+            roof["dgf_apply"] = dict(bytes=by, ms_ring=avg[i], ms_single_src=avg_single[i],
+                                     GBps_ring=by / (avg[i] * 1e-3) / 1e9, GBps_single_src=by / (avg_single[i] * 1e-3) / 1e9,
+                                     frac_of_hbm_peak_ring=by / (avg[i] * 1e-3) / HBM_PEAK)
     # HBM bytes of that launch from the committed rocprofv3 --pmc passes of this same command
     # (FETCH_SIZE + WRITE_SIZE, separate passes; DESIGN.md "Measurement" has the gfx950 calibration note)
-    pmc = os.path.join(ROOT, PMC_FILES.get(wl_key, ""))
-    if batch == 1 and chunk == 1 and a.dtype == "fp16" and os.path.isfile(pmc):
+    tag = PROFILE_TAGS.get((wl_key, batch, chunk))
+    pmc = os.path.join(ROOT, PROFILE_DIR, "pmc_%s.json" % tag) if tag else ""
+    if tag and a.dtype == "fp16" and os.path.isfile(pmc):
         for e in json.load(open(pmc)):
             if e["name"] == name:
                 roof["traffic"] = e["fetch_bytes"] + e["write_bytes"]
-                roof["traffic_source"] = PMC_FILES[wl_key] + " (" + e.get("fetch_note", "raw FETCH_SIZE") + ")"
+                roof["traffic_source"] = "%s/pmc_%s.json (%s)" % (PROFILE_DIR, tag, e.get("fetch_note", "raw FETCH_SIZE"))
     # ... and the committed rocprofv3 --kernel-trace mean duration of the same launch: the hipEvent figure above carries the
     # spacing of two event records (~2-3 us more than the kernel's own begin-to-end time), so both are shown
-    trace = os.path.join(ROOT, TRACE_FILES.get(wl_key, ""))
-    if batch == 1 and chunk == 1 and a.dtype == "fp16" and os.path.isfile(trace):
+    trace = os.path.join(ROOT, PROFILE_DIR, "%s_kernel_trace_table.txt" % tag) if tag else ""
+    if tag and a.dtype == "fp16" and os.path.isfile(trace):
         import re
         for line in open(trace):
             m = re.match(r"\s+(\S+)\s+([\d.]+) us", line)
@@ -199,19 +295,23 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
                 roof["rocprof_kernel_ms"] = float(m.group(2)) * 1e-3
                 roof["rocprof_frac"] = (flops if roof["bound"] == "mfma" else nbytes) / (float(m.group(2)) * 1e-6) / \
                     (MFMA_PEAK[a.dtype] if roof["bound"] == "mfma" else HBM_PEAK)
-                roof["rocprof_source"] = TRACE_FILES[wl_key]
+                roof["rocprof_source"] = "%s/%s_kernel_trace_table.txt" % (PROFILE_DIR, tag)
     if dump:
         os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
         with open(dump, "w") as f:
-            json.dump([dict(name=n, ms=m, flops=fl, bytes=by, kernels=nk)
-                       for (n, fl, by), m, nk in zip(info, avg, ctx.launch_kernels())], f, indent=1)
+            json.dump([dict(name=n, ms=m, ms_single_src=m1, flops=fl, bytes=by, kernels=nk)
+                       for (n, fl, by), m, m1, nk in zip(info, avg, avg_single, ctx.launch_kernels())], f, indent=1)
     res["roofline"] = roof
+    # frame level: SURVEY 8(d)'s algorithmic bytes and the schedule's algorithmic FLOPs per frame against the two peaks
     h, w = spec.lowres_size(wl["H"], wl["W"], ds)
-    es = 4 if a.dtype == "fp32" else 2
     balg = frame_algorithmic_bytes(wl["H"], wl["W"], h, w, es, variant)
+    falg = sum(fl for _, fl, _ in info) / (batch * chunk)
     per_gpu = fps / world
     res["frame_roofline"] = {"algorithmic_bytes_per_frame": balg, "achieved_GBps": balg * per_gpu / 1e9,
-                             "frac_of_hbm_peak": balg * per_gpu / HBM_PEAK}
+                             "frac_of_hbm_peak": balg * per_gpu / HBM_PEAK,
+                             "algorithmic_flops_per_frame": falg, "achieved_TFLOPps": falg * per_gpu / 1e12,
+                             "frac_of_mfma_peak": falg * per_gpu / MFMA_PEAK[a.dtype]}
+    res["memory_bytes"] = ctx.memory_bytes()
     del model, runner
     return res
 
@@ -230,6 +330,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU (BASELINE configs[4]: --gpus 8 --batch 8)")
     ap.add_argument("--chunk", type=int, default=1,
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
+    ap.add_argument("--src-ring", type=int, default=0,
+                    help="distinct step inputs cycled through (0: as many as exceed the 256 MiB Infinity Cache; 1: the same input every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under 'also' at N=1")
     ap.add_argument("--dump-kernels", default="")
@@ -270,8 +372,8 @@ def main():
             also = {}
             for key, wlk, b in (("4k", "4k", 1), ("hd_batch8", "hd", 8), ("hd_resnet50", "hd_resnet50", 1)):
                 r = measure(a, wlk, b, 1, 100, 10, dev, 0, 1, None)
-                also[key] = dict(fps=r["fps"], ms_per_step=r["ms_per_step"], steps=r["steps"], workload=r["workload"],
-                                 streams_per_gpu=b, roofline=r["roofline"], frame_roofline=r["frame_roofline"])
+                also[key] = {k: r[k] for k in ("fps", "ms_per_step", "steps", "workload", "streams_per_gpu", "src_ring", "fps_single_src",
+                                               "fps_sync_every_frame", "roofline", "frame_roofline", "memory_bytes")}
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(WORKLOADS[a.workload])
             if default_cfg and not a.no_also:
@@ -287,10 +389,17 @@ def main():
                       "bf16": "bf16 tensors (MFMA on split hi/lo f16 operands, f32 accumulate)"}[a.dtype],
             "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "frames_per_step": a.batch * a.chunk, "chunk": a.chunk, "mode": a.mode,
+                       "src_ring": head["src_ring"],
                        "parallelism": "stream-sharded, %d independent stream(s), no collective" % (world * a.batch)},
             "roofline": head["roofline"], "cpu_baseline": cpu,
             "frame_roofline": head["frame_roofline"],
+            # the same workload under the other two protocols (this rank): one input re-used every step (rounds 1-2; src then
+            # stays in the 256 MiB Infinity Cache) and the reference's loop with a device synchronisation after every frame
+            "fps_single_src": head["fps_single_src"], "fps_sync_every_frame": head["fps_sync_every_frame"],
+            "memory_bytes": head.get("memory_bytes"),
         }
+        if "fps_per_rank" in head:
+            line["fps_per_rank"] = head["fps_per_rank"]
         if also is not None:
             line["also"] = also
         if cpu_small is not None:

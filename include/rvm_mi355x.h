@@ -65,6 +65,16 @@ int rvm_plan(rvm_ctx* ctx, int B, int H, int W, double downsample_ratio);
  * ([T][B][C][H][W], frame t of stream b at index t*B + b) and r_in / r_out as [B,C,h,w]: the state
  * before frame 0 and after frame T-1.  rvm_plan(B, ...) == rvm_plan_seq(B, 1, ...). */
 int rvm_plan_seq(rvm_ctx* ctx, int B, int T, int H, int W, double downsample_ratio);
+/* Memory.  The arena of a plan, the weight blob and the scratch of plan-time measurement are hipMalloc'd by the library (a
+ * torch-free C ABI cannot borrow torch's caching allocator), never on the frame path.  A context keeps the active plan plus up
+ * to RVM_KEEP_PLANS (environment, 0..8, default 4) parked ones so that a driver alternating call shapes (convert_video's short
+ * last chunk; 4-D and 5-D calls in turn) neither re-allocates nor re-measures; each holds its own arena (HD, one frame:
+ * ~45 MB; 8 batched HD streams: ~0.36 GB; an HD chunk of 12: ~0.5 GB).  rvm_memory_bytes reports the device bytes a context
+ * holds (total; the three parts through the optional pointers), rvm_trim frees the parked plans (synchronises the device).
+ * No counterpart in the reference (PyTorch's allocator owns its activations). */
+int64_t rvm_memory_bytes(const rvm_ctx* ctx, int64_t* weights, int64_t* active_plan, int64_t* parked_plans);
+int rvm_trim(rvm_ctx* ctx);
+
 /* level = 1..4 -> {B, C, h, w} of r<level> for the current plan. */
 int rvm_state_shape(const rvm_ctx* ctx, int level, int64_t shape[4]);
 

@@ -182,12 +182,75 @@ def e2e(variant, refiner, tag, H, W, ds, T, seed):
         fgr_last=fgr[:, -1].numpy(), r1=rec[0].numpy(), r2=rec[1].numpy(), r3=rec[2].numpy(), r4=rec[3].numpy())
 
 
+def encoder_tables():
+    """What the reference ITSELF holds about the encoders and the glue, read as literals with `ast` - nothing is imported
+    or run (model/mobilenetv3.py, model/resnet.py and model/model.py need torchvision, which is absent): the 15
+    InvertedResidualConfig rows and last_channel (mobilenetv3.py:9-27), the normalisation constants (:37), the feature
+    taps (:39-59); ResNet50's layers / dilation flags (resnet.py:7-11) and taps (:20-33); the LR-ASPP / decoder widths of
+    both variants (model.py:25-30).  Written to tests/golden/ref_encoder_tables.json; tests/test_encoder_tables.py holds
+    the oracle's, the Python spec's and the native library's tables against it."""
+    import ast
+    import json
+
+    def lit(node):
+        return ast.literal_eval(node)
+
+    out = {}
+    tree = ast.parse(open(os.path.join(REF, "mobilenetv3.py")).read())
+    rows, taps, last, mean, std = [], {}, None, None, None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "id", None) == "InvertedResidualConfig":
+            rows.append([lit(a) for a in node.args])
+        if isinstance(node, ast.keyword) and node.arg == "last_channel":
+            last = lit(node.value)
+        if isinstance(node, ast.Call) and getattr(node.func, "id", None) == "normalize":
+            mean, std = lit(node.args[1]), lit(node.args[2])
+    fwd = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "forward_single_frame"][0]
+    cur = None
+    for st in fwd.body:
+        if isinstance(st, ast.Assign) and isinstance(st.value, ast.Call) and isinstance(st.value.func, ast.Subscript):
+            cur = lit(st.value.func.slice)                      # x = self.features[i](x)
+        elif isinstance(st, ast.Assign) and isinstance(st.value, ast.Name) and st.targets[0].id.startswith("f"):
+            taps[st.targets[0].id] = cur                        # fK = x
+    out["mobilenetv3"] = dict(inverted_residual_setting=rows, last_channel=last, normalize_mean=mean, normalize_std=std,
+                              taps_after_feature=taps, num_features=cur + 1)
+    tree = ast.parse(open(os.path.join(REF, "resnet.py")).read())
+    kw = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.keyword) and node.arg in ("layers", "replace_stride_with_dilation"):
+            kw[node.arg] = lit(node.value)
+        if isinstance(node, ast.keyword) and node.arg == "block":
+            kw["block"] = node.value.id
+    fwd = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "forward_single_frame"][0]
+    order, rtaps, cur = [], {}, None
+    for st in fwd.body:
+        if isinstance(st, ast.Assign) and isinstance(st.value, ast.Call) and isinstance(st.value.func, ast.Attribute):
+            cur = st.value.func.attr                            # x = self.<module>(x)
+            order.append(cur)
+        elif isinstance(st, ast.Assign) and isinstance(st.value, ast.Name) and st.targets[0].id.startswith("f"):
+            rtaps[st.targets[0].id] = cur
+    out["resnet50"] = dict(kw, module_order=order, taps_after_module=rtaps)
+    tree = ast.parse(open(os.path.join(REF, "model.py")).read())
+    glue = {"LRASPP": [], "RecurrentDecoder": [], "Projection": []}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "id", None) in glue:
+            glue[node.func.id].append([lit(a) for a in node.args])
+    out["model"] = glue                                         # [mobilenetv3, resnet50] order of the if / else in model.py:24-30
+    with open(os.path.join(OUT, "ref_encoder_tables.json"), "w") as f:
+        json.dump(out, f, sort_keys=True)
+    print("ref_encoder_tables.json:", len(rows), "rows; taps", taps, rtaps)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if "--chunk-only" in sys.argv:
         ref_decoder_chunk()
         sys.exit(0)
+    if "--tables-only" in sys.argv:
+        encoder_tables()
+        sys.exit(0)
+    encoder_tables()
     ref_blocks("mobilenetv3")
     ref_blocks("resnet50")
     ref_decoder_chunk()

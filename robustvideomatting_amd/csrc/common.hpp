@@ -92,6 +92,32 @@ struct EdArgs {
     const float* pj_w; const float* pj_b;   // [16 in][16 out] fp32 (BN folded), [16]; null: none.  y is then the block's output
 };
 
+// ---- whole inverted-residual block without squeeze-excite in one launch (mbconv_fused.hip) ---------------
+// 1x1 expand (MFMA) -> depthwise 3x3 (LDS) -> 1x1 project (MFMA) [+ residual] per tile of output pixels; the expanded
+// tensor and the depthwise output never leave the CU.
+struct MbfArgs {
+    const void* x; int Cin;                 // block input [N][Hi*Wi][Cin]
+    const void* we; int KSe, NTe;           // expand weight fragments [NTe][KSe][512]
+    const float* ebias; int act;            // [NTe*16]; activation of the expand and the depthwise conv (ReLU / hardswish)
+    const float* dw_w; const float* dw_b;   // [9][C], [C] (BN folded)
+    const void* wp; int KSp, NTp;           // project weight fragments [NTp][KSp][512]
+    const float* pbias;                     // [NTp*16]
+    const void* res;                        // residual [N][Ho*Wo][Cout] (the block input) or null
+    void* y; int Cout;                      // block output [N][Ho*Wo][Cout]
+    int C;                                  // expanded channels (multiple of 4)
+    int Hi, Wi, Ho, Wo, stride;
+    int THo, TWo, tiles_x, tiles_y;         // output tile (powers of two, THo even, THo * TWo in {16, 32})
+    // derived by mbf_prepare (host): halo geometry and the LDS map, so that the kernel computes none of it
+    int THi, TWi, NPXi, MTe, npx, TP, MTp, CSLx, CSLd, Cq, KP, ngE, padq, twl, hpl;
+    unsigned invTWi, invCq;
+    int mulE, mulP;
+    int off_e, off_d, off_w, lds_total, red_bytes;
+};
+bool mbf_supported(int stride, int KSe, int act);    // a kernel instantiation exists for the combination
+bool mbf_prepare(MbfArgs& a, int es);                // fills the derived fields; false: the tile does not fit the kernel
+template <typename T> void launch_mbf(const MbfArgs& a, int N, hipStream_t s);
+void mbf_init();                                     // one-time function attributes
+
 // ---- small dense layer on pooled vectors (SE fc1/fc2, LR-ASPP gate) ------------------------
 struct GemvArgs {
     const float* xin; int nparts; int part_stride; float xscale;   // x[i] = xscale * sum_p xin[(n*nparts+p)*part_stride+i]

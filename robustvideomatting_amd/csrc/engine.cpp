@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -807,8 +808,15 @@ int build_plan(rvm_ctx* c) {
         // slices (8, 9, 10), then the same with 128-pixel tiles (11; split 2 / 4: 12, 13).  The latency model only knows
         // 0..6; the others are taken where plan-time measurement finds them faster.
         const bool lds_ok = !in_scale && !ex.se_hpart;
-        const bool split_ok = lds_ok && !pool && !out_scale && (int64_t)B * 8 <= 65535;
+        // (split-K only where the unsplit grid leaves CUs idle: <= 512 block tiles; the sizing pass then reserves the
+        //  partial-sum workspace of the widest split on offer, so that plan-time measurement can try every candidate)
+        const bool split_ok = lds_ok && !pool && !out_scale && (int64_t)B * 8 <= 65535 && (int64_t)cdiv(a.MT, 4) * cdiv(a.NT, 4) * B <= 512;
         const int ncand = lds_ok ? (split_ok ? 14 : 8) : 7;
+        if (split_ok) {
+            int widest = 0;
+            for (int ns = 8; ns >= 2; ns >>= 1) if (a.KS >= 2 * ns) { widest = ns; break; }
+            if (widest) c->split_need = std::max(c->split_need, (size_t)widest * B * HW * L.NT * 16 * sizeof(float));
+        }
         int cfg = tune_pick(name, ncand, pick_pw_cfg(a.MT, a.NT, a.KS, B));
         if (const char* e = getenv("RVM_PW_CFG")) {               // test hook: force one configuration wherever it is a candidate
             const int v = atoi(e);
@@ -1054,6 +1062,62 @@ int build_plan(rvm_ctx* c) {
             const int exp = b.row.exp;
             const int K = b.dw.K;
             const int npix = Ho * Wo;
+            // ---- blocks without squeeze-excite (features[2], [3], [7]..[10]): the whole block in one launch (mbconv_fused.hip)
+            //      - expand, depthwise and project per tile of output pixels, nothing but the block's input and output in memory
+            if (b.has_expand && !b.has_se && !b.pj && K == 3 && b.dw.dil == 1 && b.expand.act == b.dw.act &&
+                mbf_supported(b.dw.stride, b.expand.KS, b.expand.act) && !(getenv("RVM_MB_FUSE") && atoi(getenv("RVM_MB_FUSE")) == 0)) {
+                MbfArgs a; memset(&a, 0, sizeof a);
+                a.x = cur; a.Cin = curC;
+                a.we = wb + b.expand.w; a.KSe = b.expand.KS; a.NTe = b.expand.NT; a.ebias = (const float*)(wb + b.expand.bias); a.act = b.expand.act;
+                a.dw_w = (const float*)(wb + b.dw.w); a.dw_b = (const float*)(wb + b.dw.bias);
+                a.wp = wb + b.project.w; a.KSp = b.project.KS; a.NTp = b.project.NT; a.pbias = (const float*)(wb + b.project.bias);
+                a.res = b.res ? cur : nullptr; a.Cout = b.row.cout; a.C = exp;
+                a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride;
+                // Tile candidates (rows x columns of output pixels).  One frame: the launch is a chain of round trips, so
+                // the smallest per-block work that still keeps the grid within one round of CUs wins; many frames: plan-time
+                // measurement decides (larger tiles recompute less halo).
+                static const int cand[9][2] = {{2, 8}, {4, 4}, {4, 8}, {2, 16}, {8, 4}, {4, 16}, {8, 8}, {2, 32}, {16, 4}};
+                int valid[9], nvalid = 0, model = -1;
+                double best = 1e30;
+                for (int k = 0; k < 9; ++k) {
+                    a.THo = cand[k][0]; a.TWo = cand[k][1];
+                    if (!mbf_prepare(a, (int)es)) continue;
+                    const int thi = (a.THo - 1) * a.stride + 3, twi = (a.TWo - 1) * a.stride + 3, mte = cdiv(thi * twi, 16), tp = a.THo * a.TWo;
+                    const int blocks = cdiv(Ho, a.THo) * cdiv(Wo, a.TWo) * B;
+                    const int nge = a.ngE, npw = a.NTe > 8 ? 2 : 1;
+                    // cycles of the three phases of one block (MFMA issue + LDS traffic, fitted by eye; refined by measurement on the box)
+                    const double cyc = (double)cdiv(mte, nge) * npw * (48.0 * a.KSe * (split ? 3 : 1) + 120.0) + (double)cdiv((exp / 4) * tp / 2, 512) * 500.0 +
+                                       (double)cdiv(a.KSp, a.KP) * (tp / 16) * (48.0 * (split ? 3 : 1) + 40.0) + 600.0;
+                    const double cost = (double)cdiv(blocks, 256) * (3.2 + cyc / 2000.0);
+                    if (cost < best - 1e-9) { best = cost; model = nvalid; }
+                    valid[nvalid++] = k;
+                }
+                if (nvalid > 0) {
+                    int pick = valid[tune_pick("mb" + std::to_string(i + 1) + ".fused", nvalid, model)];
+                    if (const char* e = getenv("RVM_MBF_TILE")) {       // test hook: "rows,cols" forces that tile where it is valid
+                        int th = 0, tw = 0;
+                        if (sscanf(e, "%d,%d", &th, &tw) == 2)
+                            for (int k = 0; k < nvalid; ++k) if (cand[valid[k]][0] == th && cand[valid[k]][1] == tw) pick = valid[k];
+                    }
+                    a.THo = cand[pick][0]; a.TWo = cand[pick][1];
+                    a.tiles_x = cdiv(Wo, a.TWo); a.tiles_y = cdiv(Ho, a.THo);
+                    if (!mbf_prepare(a, (int)es)) return fail("mbconv_fused: tile preparation failed");
+                    T* out = abuf((size_t)B * npix * b.row.cout);
+                    a.y = out;
+                    if (getenv("RVM_VERBOSE") && c->arena)
+                        fprintf(stderr, "[rvm] mb%d.fused tile %dx%d blocks %d lds %zu\n", i + 1, a.THo, a.TWo, a.tiles_x * a.tiles_y * B, (size_t)a.lds_total);
+                    add("mb" + std::to_string(i + 1) + ".fused",
+                        2.0 * B * ((double)Hi * Wi * curC * exp + (double)npix * exp * 9 + (double)npix * exp * b.row.cout),
+                        ((double)B * (Hi * Wi * curC + npix * b.row.cout * (b.res ? 2 : 1)) + (double)curC * exp + 10.0 * exp + (double)exp * b.row.cout) * es,
+                        [=](hipStream_t st, const FrameIO&) {
+                            if constexpr (std::is_same<T, float>::value) { if (split) { launch_mbf<f32s>(a, B, st); return; } }
+                            launch_mbf<T>(a, B, st);
+                        });
+                    cur = out; curC = b.row.cout; lvl = olvl;
+                    if (i == 2) f[1] = cur;
+                    continue;
+                }
+            }
             T* dwo = b.pj ? nullptr : abuf((size_t)B * npix * exp);
             T* pj_done = nullptr;                              // block 1: the fused launch already wrote the block's output
             PwX se_x;                                          // squeeze-excite tail handed to the project GEMM (small SE layers)
@@ -1482,7 +1546,9 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
             return 0;
         }
     }
-    while (c->parked.size() > 4) {                      // least recently used first
+    size_t keep = 4;                                    // parked plans kept beside the active one (RVM_KEEP_PLANS=0..8)
+    if (const char* e = getenv("RVM_KEEP_PLANS")) keep = (size_t)std::min(8, std::max(0, atoi(e)));
+    while (c->parked.size() > keep) {                   // least recently used first
         HIPCHK(hipDeviceSynchronize());
         for (auto& g : c->parked.front().graphs) (void)hipGraphExecDestroy(g.exec);
         if (c->parked.front().arena) HIPCHK(hipFree(c->parked.front().arena));
@@ -1540,8 +1606,20 @@ int rvm_create(int variant, int refiner, int dtype, int device, rvm_ctx** out) {
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("rvm_create: no such HIP device");
     DEVGUARD(device);
-    static bool inited[64] = {false};
-    if (device < 64 && !inited[device]) { kernels_init(); inited[device] = true; }
+    {
+        // once per device, with that device current: function attributes (dynamic LDS limits) and the address of the
+        // allocation-free entry point's static scratch array (so that its first call on this device can run where nothing
+        // may be looked up any more, e.g. under graph capture).  Contexts may be created from several host threads.
+        static std::mutex init_mu;
+        static bool inited[64] = {false};
+        std::lock_guard<std::mutex> lock(init_mu);
+        if (device < 64 && !inited[device]) {
+            kernels_init();
+            float* scratch_ptr = nullptr;
+            if (metrics_scratch(&scratch_ptr)) return fail("rvm_create: hipGetSymbolAddress(scratch) failed");
+            inited[device] = true;
+        }
+    }
     rvm_ctx* c = new rvm_ctx();
     c->variant = variant; c->refiner = refiner; c->dtype = dtype; c->device = device;
     if (dtype == RVM_DTYPE_F16IO || dtype == RVM_DTYPE_BF16IO) {
@@ -1617,6 +1695,26 @@ int rvm_state_shape(const rvm_ctx* c, int level, int64_t shape[4]) {
     return 0;
 }
 
+int rvm_trim(rvm_ctx* c) {
+    if (!c) return fail("rvm_trim: null ctx");
+    DEVGUARD(c->device);
+    if (c->parked.empty()) return 0;
+    HIPCHK(hipDeviceSynchronize());                       // a parked plan's graphs / arena may still be in flight
+    c->free_parked();
+    return 0;
+}
+
+int64_t rvm_memory_bytes(const rvm_ctx* c, int64_t* weights, int64_t* active_plan, int64_t* parked_plans) {
+    if (!c) return -1;
+    const int64_t w = c->wdev ? (int64_t)c->blob.size() : 0, a = c->arena ? (int64_t)c->arena_bytes : 0;
+    int64_t p = 0;
+    for (const auto& k : c->parked) p += k.arena ? (int64_t)k.arena_bytes : 0;
+    if (weights) *weights = w;
+    if (active_plan) *active_plan = a;
+    if (parked_plans) *parked_plans = p;
+    return w + a + p;
+}
+
 int rvm_launch_count(const rvm_ctx* c) { return c ? (int)c->launches.size() : 0; }
 int rvm_launch_kernels(const rvm_ctx* c, int i) { return (c && i >= 0 && i < (int)c->launches.size()) ? c->launches[i].nk : 0; }
 
@@ -1685,11 +1783,21 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
         for (size_t i = lo; i < hi; ++i) c->launches[i].fn(c->cap_stream, io);
-        HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
-        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        // whatever happened in between, the capture is ended here: a stream left capturing would poison every later call
+        const hipError_t launch_err = hipGetLastError();
+        const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);
+        if (launch_err != hipSuccess || end_err != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            return fail(std::string("rvm_forward: graph capture failed: ") + hipGetErrorString(launch_err != hipSuccess ? launch_err : end_err));
+        }
+        const hipError_t inst_err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
+        if (inst_err != hipSuccess) return fail(std::string("rvm_forward: hipGraphInstantiate: ") + hipGetErrorString(inst_err));
         if (c->graphs.size() >= 8) {
-            HIPCHK(hipStreamSynchronize(st));                  // the evicted exec may still be running there
+            // the evicted exec may still be running on whichever stream it was last launched on
+            const hipError_t sync_err = hipDeviceSynchronize();
+            if (sync_err != hipSuccess) { (void)hipGraphExecDestroy(exec); return fail(std::string("rvm_forward: ") + hipGetErrorString(sync_err)); }
             (void)hipGraphExecDestroy(c->graphs.front().exec);
             c->graphs.erase(c->graphs.begin());
         }

@@ -18,7 +18,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 # every symbol include/rvm_mi355x.h declares
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
-    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_state_shape", "rvm_forward", "rvm_forward_u8",
+    "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_memory_bytes", "rvm_trim", "rvm_state_shape", "rvm_forward", "rvm_forward_u8",
     "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_kernels", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
 ]
 
@@ -60,6 +60,10 @@ def lib():
     L.rvm_plan.restype = ci
     L.rvm_plan_seq.argtypes = [vp, ci, ci, ci, ci, ctypes.c_double]
     L.rvm_plan_seq.restype = ci
+    L.rvm_memory_bytes.argtypes = [vp, i64p, i64p, i64p]
+    L.rvm_memory_bytes.restype = ctypes.c_int64
+    L.rvm_trim.argtypes = [vp]
+    L.rvm_trim.restype = ci
     L.rvm_state_shape.argtypes = [vp, ci, i64p]
     L.rvm_state_shape.restype = ci
     L.rvm_forward.argtypes = [vp, vp, cpp, vp, vp, cpp, ci, vp]
@@ -192,6 +196,16 @@ class Context:
         if key != self.plan_key:
             check(lib().rvm_plan_seq(self._h, B, T, H, W, float(ds)), "rvm_plan_seq")
             self.plan_key = key
+
+    def memory_bytes(self):
+        """Device bytes the context holds: dict(total, weights, active_plan, parked_plans)."""
+        w, a, p = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        tot = lib().rvm_memory_bytes(self._h, ctypes.byref(w), ctypes.byref(a), ctypes.byref(p))
+        return dict(total=tot, weights=w.value, active_plan=a.value, parked_plans=p.value)
+
+    def trim(self):
+        """Free the plans kept for shapes not in use (rvm_trim)."""
+        check(lib().rvm_trim(self._h), "rvm_trim")
 
     def state_shape(self, level):
         shape = (ctypes.c_int64 * 4)()

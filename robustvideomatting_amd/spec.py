@@ -2,8 +2,10 @@
 
 Single source of truth (on the Python side) for layer shapes and for the
 ``state_dict`` key layout the drop-in boundary has to honour.  The native
-engine (csrc/engine.cpp) carries the same tables in C++; tests/test_spec.py
-checks that the two agree through ``rvm_param_count`` / ``rvm_param_name``.
+engine (csrc/engine.cpp) carries the same tables in C++; tests/test_c_abi_gpu.py
+checks that the two agree through ``rvm_param_count`` / ``rvm_param_name``, and
+tests/test_encoder_tables.py holds both against the reference's own literals
+(tests/golden/ref_encoder_tables.json).
 
 Reference for the numbers:
   * MobileNetV3-Large rows  - /root/reference/model/mobilenetv3.py:9-27

@@ -4,10 +4,14 @@ The fixed-shape tests exercise the benchmark sizes; this one walks band / tile /
 hand (tiny pyramids that collapse to 1 x 2, widths that are not multiples of anything, ratios between 0.2 and 1).  The case
 list is generated from a fixed seed, so a failure names a reproducible case.
 """
+import os
 import random
+import sys
 
 import pytest
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +56,10 @@ def test_random_case_against_oracle(case):
     ref = dev.float().cpu()
     tol = TOL[dtype]
     if refiner == "fast_guided_filter":
-        tol = max(tol, 2e-3)                        # cov / (var + 1e-5): ill-conditioned, see test_fp32_fast_guided_filter
+        # cov / (var + 1e-5) is ill-conditioned: the mode's tolerance, or 3x the fp32 oracle's own distance to fp64 on this
+        # very clip if that is larger (gpu_check.fast_gf_bound) - not a blanket bound
+        import gpu_check
+        tol, _ = gpu_check.fast_gf_bound(p, ref, ds, tol, variant)
     rg, ro = [None] * 4, [None] * 4
     chunked = i % 3 == 0 and T > 1                  # every third case: the clip as one [B,T,...] call
     with torch.no_grad():

@@ -39,11 +39,14 @@ def _both(L, N, H, W, seed, fgr, prev):
     rc = L.rvm_metrics(P(pred), P(true), P(pp), P(tp), P(pf), P(tf), N, H, W, 1.4, P(ws), P(want), stream)
     assert rc == 0, L.rvm_last_error()
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # no allocation of ANY kind: torch's counter only sees its own caching allocator, so the device's free memory
+    # (hipMemGetInfo) is compared as well - a hipMalloc inside the library would show there
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     rc = L.rvm_metrics_static(P(pred), P(true), P(pp), P(tp), P(pf), P(tf), N, H, W, 1.4, P(got), stream)
     assert rc == 0, L.rvm_last_error()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before
     return want.cpu(), got.cpu()
 
 

@@ -13,6 +13,18 @@ sys.path.insert(0, ROOT)
 from oracle import rvm_oracle as O                        # noqa: E402  (checker only)
 from robustvideomatting_amd import MattingNetwork, synthetic   # noqa: E402
 
+def fast_gf_bound(params, clip_ref, ds, tol, variant="mobilenetv3"):
+    """Parity bound for the FAST guided filter (fast_guided_filter.py:55: A = cov / (var + 1e-5)): the division is
+    ill-conditioned where var ~ eps, so the reference's own fp32 arithmetic sits a few 1e-5..1e-3 away from the same
+    arithmetic in fp64, depending on the clip.  Bound = the mode's tolerance, or 3x the fp32 oracle's own distance to the
+    fp64 oracle on THIS clip if that is larger (clip_ref: [B,T,3,H,W] fp32, what the device sees)."""
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    o32 = O.forward(params, clip_ref, downsample_ratio=ds, variant=variant, refiner="fast_guided_filter")
+    o64 = O.forward(p64, clip_ref.double(), downsample_ratio=ds, variant=variant, refiner="fast_guided_filter")
+    own = max((o32[0].double() - o64[0]).abs().max().item(), (o32[1].double() - o64[1]).abs().max().item())
+    return max(tol, 3.0 * own), own
+
+
 TAPS = ["s0", "s1", "s2", "s3", "f1", "f2", "f3", "f4", "aspp", "x3", "x2", "x1", "hid", "ab"]
 
 
