@@ -316,6 +316,59 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     return res
 
 
+class _NullWriter:
+    """Counts the frames it is handed (a stand-in for an encoder: codecs are out of scope)."""
+
+    def __init__(self):
+        self.frames = 0
+        self.checksum = 0
+
+    def write(self, frames_u8):
+        self.frames += frames_u8.shape[0]
+        self.checksum += int(frames_u8[0, 0, 0, 0])
+
+    def close(self):
+        pass
+
+
+def driver_pipeline(a, dev, wl_key="4k", T=24, chunk=4):
+    """PCIe-inclusive rate of the driver loop (convert_video: host frames in, composed uint8 frames out) on an
+    in-memory clip: the tensor-throughput `value` excludes host traffic like the reference's protocol does; this is what a
+    caller with frames in host memory gets.  Two sources: uint8 frames (a decoder's output, 3 B / pixel up) and fp32 frames
+    (the reference reader's ToTensor output, 12 B / pixel up); 3 B / pixel down either way.  "pinned": the clip lies in
+    page-locked memory and is uploaded from where it is; otherwise every chunk is first copied into a pinned staging buffer
+    (host memcpy, ~15 GB/s on one core - the bound of that case)."""
+    from robustvideomatting_amd import inference as I
+    wl = WORKLOADS[wl_key]
+    tdt = TORCH_DTYPE[a.dtype]
+    model = MattingNetwork("mobilenetv3", "deep_guided_filter").eval()
+    model.load_state_dict(synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=0))
+    model = model.to(dev, tdt)
+    H, W = wl["H"], wl["W"]
+    base = torch.stack(list(synthetic.clip_frames(chunk, H, W, seed=0)))                  # [chunk,3,H,W] fp32
+    u8 = base.mul(255).byte().repeat(T // chunk, 1, 1, 1)                                # T frames (the chunk repeated)
+    out = {}
+    for name, clip, pin in (("uint8_source_pinned", u8, True), ("uint8_source", u8, False),
+                            ("fp32_source_pinned", u8[:max(chunk, T // 2)].float().div(255), True)):
+        n = clip.shape[0]
+        I.convert_video(model, I.TensorSource(clip[:2 * chunk]), downsample_ratio=wl["ds"], output_type="video",
+                        output_composition=_NullWriter(), seq_chunk=chunk, progress=False)     # plan + tile measurement
+        sink = _NullWriter()
+        src = I.TensorSource(clip).pin() if pin else I.TensorSource(clip)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        I.convert_video(model, src, downsample_ratio=wl["ds"], output_type="video",
+                        output_composition=sink, seq_chunk=chunk, progress=False)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert sink.frames == n
+        up = 3 * H * W * (1 if clip.dtype == torch.uint8 else 4)
+        out[name] = dict(fps=n / dt, frames=n, seq_chunk=chunk, pcie_bytes_per_frame=up + 3 * H * W,
+                         pcie_GBps=(up + 3 * H * W) * n / dt / 1e9)
+    out["workload"] = wl["name"] + ", convert_video -> green-screen composition uint8, in-memory clip"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +385,7 @@ def main():
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
     ap.add_argument("--src-ring", type=int, default=0,
                     help="distinct step inputs cycled through (0: as many as exceed the 256 MiB Infinity Cache; 1: the same input every step)")
+    ap.add_argument("--driver-pipeline", action="store_true", help="only the PCIe-inclusive convert_video rate of --workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under 'also' at N=1")
     ap.add_argument("--dump-kernels", default="")
@@ -362,6 +416,9 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if a.driver_pipeline:
+        print(json.dumps(driver_pipeline(a, dev, a.workload)))
+        return
     head = measure(a, a.workload, a.batch, a.chunk, a.steps, a.warmup, dev, rank, world, dist, a.dump_kernels)
 
     if rank == 0:
@@ -374,6 +431,7 @@ def main():
                 r = measure(a, wlk, b, 1, 100, 10, dev, 0, 1, None)
                 also[key] = {k: r[k] for k in ("fps", "ms_per_step", "steps", "workload", "streams_per_gpu", "src_ring", "fps_single_src",
                                                "fps_sync_every_frame", "roofline", "frame_roofline", "memory_bytes")}
+            also["driver_pipeline_4k"] = driver_pipeline(a, dev)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(WORKLOADS[a.workload])
             if default_cfg and not a.no_also:

@@ -9,6 +9,11 @@ tensors moved onto the device:
   (inference.py:116,137-141, inference_utils.py:44) run as ONE kernel (``rvm_compose_u8``) that
   emits uint8 frames - a quarter of the bytes that cross PCIe compared with fp16 NCHW x 4 channels.
 
+Host <-> device traffic is pipelined like the reference's (pinned source tensors, ``non_blocking`` copies, inference.py:79,127):
+the next chunk is uploaded on a side stream while the current one is computed, the finished uint8 frames come back on a third
+stream into pinned buffers and are handed to the writer one chunk later.  Sources that yield uint8 frames (``yields_uint8``)
+are uploaded as bytes and divided by 255 on the device - a quarter of the fp32 upload, same values bit for bit.
+
 Codecs are out of scope (SURVEY.md component 9): ``av`` / ``pims`` are not in this image, so a video
 FILE source or sink raises a clear error; image-sequence directories (PIL) and in-memory sources /
 sinks work.  ``torch.jit.script`` + ``freeze`` of the reference's ``Converter`` is skipped: BatchNorm
@@ -36,10 +41,11 @@ class ImageSequenceReader:
 
     frame_rate = 30
 
-    def __init__(self, path, resize: Optional[Tuple[int, int]] = None):
+    def __init__(self, path, resize: Optional[Tuple[int, int]] = None, as_uint8: bool = False):
         self.path = path
         self.files = sorted(os.listdir(path))
         self.resize = resize
+        self.yields_uint8 = as_uint8       # frames as uint8 [3,H,W]; convert_video divides by 255 on the device
 
     def __len__(self):
         return len(self.files)
@@ -52,21 +58,33 @@ class ImageSequenceReader:
         if self.resize is not None:
             img = img.resize(self.resize, Image.BILINEAR)        # transforms.Resize default interpolation
         arr = np.asarray(img, dtype=np.uint8)
-        return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255)
+        t = torch.from_numpy(arr.copy()).permute(2, 0, 1)
+        return t if self.yields_uint8 else t.float().div(255)
 
 
 class TensorSource:
-    """In-memory clip [T,3,H,W] (float 0..1) with the reader interface."""
+    """In-memory clip [T,3,H,W] (float 0..1, or uint8 0..255) with the reader interface."""
 
     def __init__(self, clip, frame_rate=30):
         self.clip = clip
         self.frame_rate = frame_rate
+        self.yields_uint8 = clip.dtype == torch.uint8
 
     def __len__(self):
         return self.clip.shape[0]
 
     def __getitem__(self, idx):
         return self.clip[idx]
+
+    def pin(self):
+        """Move the clip to page-locked host memory: convert_video then uploads its chunks straight from it, without the
+        staging copy (which at ~15 GB/s of host memcpy is what bounds a 4K stream otherwise)."""
+        self.clip = self.clip.contiguous().pin_memory()
+        return self
+
+    def chunk(self, start, stop):
+        """Frames [start, stop) as ONE tensor (a view): lets the pipeline skip the per-frame staging copy when it is pinned."""
+        return self.clip[start:stop]
 
 
 class ImageSequenceWriter:
@@ -97,7 +115,7 @@ class ListWriter:
         self.frames = []
 
     def write(self, frames_u8):
-        self.frames.extend(np.ascontiguousarray(f) for f in frames_u8)
+        self.frames.extend(np.array(f, copy=True) for f in frames_u8)      # the array handed in is a staging buffer
 
     def close(self):
         pass
@@ -174,17 +192,30 @@ def convert_video(model,
     if writer_com is not None and output_type == 'video':
         # the reference's constant, rounded like its tensor (inference.py:116)
         bgr = [float(v) for v in torch.tensor([120, 255, 155], dtype=dtype).div(255)]
+    dev = torch.device(device)
+    pipe = _Pipeline(dev) if dev.type == "cuda" else None
+    u8src = bool(getattr(source, "yields_uint8", False))
     try:
         with torch.no_grad():
             rec = [None] * 4
             n = len(source)
-            for start in range(0, n, seq_chunk):
-                chunk = torch.stack([source[i] for i in range(start, min(start + seq_chunk, n))])     # [T,3,H,W]
+            pending = None                                   # the previous chunk's outputs, still on their way to the host
+            for k, start in enumerate(range(0, n, seq_chunk)):
+                stop = min(start + seq_chunk, n)
+                whole = source.chunk(start, stop) if hasattr(source, "chunk") else None
+                frames_in = whole if (whole is not None and pipe is not None and whole.is_pinned() and whole.is_contiguous()) \
+                    else [source[i] for i in range(start, stop)]
                 if downsample_ratio is None:
-                    downsample_ratio = auto_downsample_ratio(*chunk.shape[2:])
-                src = chunk.to(device, dtype, non_blocking=True).unsqueeze(0)                          # [1,T,3,H,W]
+                    downsample_ratio = auto_downsample_ratio(*frames_in[0].shape[1:])
+                if pipe is not None:
+                    src = pipe.upload(k, frames_in, dtype, u8src).unsqueeze(0)                     # [1,T,3,H,W]
+                else:
+                    chunk = torch.stack(frames_in)
+                    chunk = chunk.float().div(255) if u8src else chunk
+                    src = chunk.to(device, dtype, non_blocking=True).unsqueeze(0)
                 # One output only and a refining ratio: the composition / byte conversion rides on the refiner's
                 # full-resolution kernel (rvm_forward_u8) - half the bytes written, no second pass over fgr / pha.
+                outs = []                                     # (writer, uint8 device frames [T,H,W,C])
                 wanted = [w for w in (writer_com, writer_pha, writer_fgr) if w is not None]
                 if len(wanted) == 1 and downsample_ratio != 1 and hasattr(model, "forward_u8"):
                     if writer_com is not None:
@@ -195,31 +226,110 @@ def convert_video(model,
                     frames = frames[0]
                     if writer_pha is not None and output_type != 'video':
                         frames = frames[..., :1]                        # to_pil_image of a 1-channel tensor: mode L
-                    wanted[0].write(frames.cpu().numpy())
-                    if progress:
-                        print("\r%d / %d frames" % (min(start + seq_chunk, n), n), end="", flush=True)
-                    continue
-                # the second src is the placeholder for the trimap (inference.py:128-129)
-                fgr, pha, *rec = model(src, src, *rec, downsample_ratio)
-                fgr, pha = fgr[0].contiguous(), pha[0].contiguous()
-                if writer_fgr is not None:
-                    writer_fgr.write(compose_u8(fgr, pha, native.COMPOSE_FOREGROUND).cpu().numpy())
-                if writer_pha is not None:
-                    a = compose_u8(None, pha, native.COMPOSE_ALPHA)
-                    if output_type != 'video':
-                        a = a[..., :1]                                  # to_pil_image of a 1-channel tensor: mode L
-                    writer_pha.write(a.cpu().numpy())
-                if writer_com is not None:
-                    mode = native.COMPOSE_GREEN if output_type == 'video' else native.COMPOSE_RGBA
-                    writer_com.write(compose_u8(fgr, pha, mode, bgr).cpu().numpy())
+                    outs.append((wanted[0], frames))
+                else:
+                    # the second src is the placeholder for the trimap (inference.py:128-129)
+                    fgr, pha, *rec = model(src, src, *rec, downsample_ratio)
+                    fgr, pha = fgr[0].contiguous(), pha[0].contiguous()
+                    if writer_fgr is not None:
+                        outs.append((writer_fgr, compose_u8(fgr, pha, native.COMPOSE_FOREGROUND)))
+                    if writer_pha is not None:
+                        a = compose_u8(None, pha, native.COMPOSE_ALPHA)
+                        if output_type != 'video':
+                            a = a[..., :1]                              # to_pil_image of a 1-channel tensor: mode L
+                        outs.append((writer_pha, a))
+                    if writer_com is not None:
+                        mode = native.COMPOSE_GREEN if output_type == 'video' else native.COMPOSE_RGBA
+                        outs.append((writer_com, compose_u8(fgr, pha, mode, bgr)))
+                # the frames start their way back now; the PREVIOUS chunk's frames (long arrived) go to the writers
+                if pipe is not None:
+                    ticket = pipe.download(k, outs)
+                    if pending is not None:
+                        pipe.deliver(pending)
+                    pending = ticket
+                else:
+                    for w, fr in outs:
+                        w.write(fr.cpu().numpy())
                 if progress:
                     print("\r%d / %d frames" % (min(start + seq_chunk, n), n), end="", flush=True)
+            if pending is not None:
+                pipe.deliver(pending)
             if progress:
                 print()
     finally:
         for w in (writer_com, writer_pha, writer_fgr):
             if w is not None:
                 w.close()
+
+
+class _Pipeline:
+    """Double-buffered host <-> device staging for convert_video: pinned buffers, an upload stream and a download stream
+    beside the compute stream (the reference pins and copies ``non_blocking``, inference.py:79,127).  Buffer set k % 2
+    serves chunk k; a set is reused only after the copies that touched it have completed (events)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.up = torch.cuda.Stream(device)
+        self.down = torch.cuda.Stream(device)
+        self.host_in = [None, None]
+        self.up_done = [None, None]
+        self.host_out = [{}, {}]
+        self.c255 = torch.full((), 255.0, device=device)
+
+    def upload(self, k, frames, dtype, u8):
+        """frames: list of [3,H,W] host tensors (staged through a pinned buffer), or ONE pinned [T,3,H,W] tensor (copied from
+        where it lies; the caller keeps it alive and unchanged until the next-but-one upload)."""
+        j = k & 1
+        cur = torch.cuda.current_stream(self.device)
+        if torch.is_tensor(frames):
+            with torch.cuda.stream(self.up):
+                d = frames.to(self.device, non_blocking=True)
+                d = torch.div(d.float(), self.c255).to(dtype) if u8 else d.to(dtype)
+                ev = self.up.record_event()
+            cur.wait_event(ev)
+            d.record_stream(cur)
+            return d
+        T, shape = len(frames), tuple(frames[0].shape)
+        buf = self.host_in[j]
+        if buf is None or buf.shape[1:] != shape or buf.shape[0] < T or buf.dtype != frames[0].dtype:
+            buf = self.host_in[j] = torch.empty((T,) + shape, dtype=frames[0].dtype).pin_memory()
+        if self.up_done[j] is not None:
+            self.up_done[j].synchronize()                   # the copy that last read this buffer
+        for t, f in enumerate(frames):
+            buf[t].copy_(f)
+        with torch.cuda.stream(self.up):
+            d = buf[:T].to(self.device, non_blocking=True)
+            # uint8 frames: ToTensor's `/ 255` in fp32, then the model dtype (reference inference.py:66-70,127) - on the device
+            # (a tensor divisor: with a Python scalar torch multiplies by the rounded reciprocal on the GPU, one ulp off the CPU's division)
+            d = torch.div(d.float(), self.c255).to(dtype) if u8 else d.to(dtype)
+            self.up_done[j] = self.up.record_event()
+        cur.wait_event(self.up_done[j])
+        d.record_stream(cur)
+        return d
+
+    def download(self, k, outs):
+        j = k & 1
+        cur = torch.cuda.current_stream(self.device)
+        done = cur.record_event()
+        ticket = []
+        with torch.cuda.stream(self.down):
+            self.down.wait_event(done)
+            for idx, (w, fr) in enumerate(outs):
+                key = (idx, tuple(fr.shape[1:]))
+                host = self.host_out[j].get(key)
+                if host is None or host.shape[0] < fr.shape[0]:
+                    host = self.host_out[j][key] = torch.empty(fr.shape, dtype=torch.uint8).pin_memory()
+                host[:fr.shape[0]].copy_(fr, non_blocking=True)
+                fr.record_stream(self.down)
+                ticket.append((w, host, fr.shape[0]))
+            ev = self.down.record_event()
+        return ev, ticket
+
+    def deliver(self, pending):
+        ev, ticket = pending
+        ev.synchronize()
+        for w, host, T in ticket:
+            w.write(host[:T].numpy())
 
 
 class Converter:

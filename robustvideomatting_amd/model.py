@@ -98,6 +98,7 @@ class MattingNetwork(nn.Module):
         self._live = None           # live floating-point parameter / buffer tensors, for the in-place edit check
         self._live_sig = None       # (sum of their _version counters, sum of data_ptr) at the last upload
         self._calls = 0
+        self.edit_check_interval = 64   # under no_grad, look for in-place parameter edits every N-th call (see _check_in_place_edits)
 
     # ---- bookkeeping: any .to()/.half()/.cuda()/load_state_dict invalidates the packed weights.
     # fp32 MASTER copies of the parameters are kept across .half(): the native packer folds
@@ -128,20 +129,23 @@ class MattingNetwork(nn.Module):
         self._dirty = True
 
     def _signature(self):
+        # the LIVE parameter / buffer objects (not state_dict aliases: those keep pointing at the old storage when a
+        # parameter's .data is rebound): version counters catch in-place ops, data_ptr catches `p.data = ...`
         if self._live is None:
-            self._live = [v for v in self.state_dict().values() if v.is_floating_point()]
+            self._live = [p for p in self.parameters()] + [b for b in self.buffers() if b.is_floating_point()]
         return (sum(v._version for v in self._live), sum(v.data_ptr() for v in self._live))
 
     def _check_in_place_edits(self):
-        """In-place edits of the live parameters (an optimiser step, ``p.mul_()``, ``p.data = ...``) make the fp32
-        masters stale: compare the tensors' version counters / storage with what was uploaded and, on a change, drop
-        the masters and re-pack.  Checked on every call while autograd is enabled and on every 64th call under
-        ``torch.no_grad()`` (the inference loop); writes through ``p.data.copy_()`` bump no counter - call
-        ``refresh()`` after those."""
+        """In-place edits of the live parameters (an optimiser step, ``p.mul_()``, an EMA ``copy_``, ``p.data = ...``) make
+        the packed weights stale: compare the tensors' version counters / storage with what was uploaded and, on a change,
+        drop the fp32 masters and re-pack.  Checked on every call while autograd is enabled and on every
+        ``edit_check_interval``-th call (default 64; 1 = every call, ~40 us of host time) under ``torch.no_grad()``, the
+        inference loop - so up to 63 frames may still use the old weights; call ``refresh()`` right after an edit to
+        re-pack at once.  Writes through ``p.data.copy_()`` bump no counter at all - ``refresh()`` is the only way."""
         self._calls += 1
         if self._dirty or self._live_sig is None:
             return
-        if not torch.is_grad_enabled() and (self._calls & 63):
+        if not torch.is_grad_enabled() and (self._calls % max(1, int(self.edit_check_interval))):
             return
         if self._signature() != self._live_sig:
             self._master = None

@@ -154,3 +154,50 @@ def test_convert_video_png_sequence_matches_oracle_pipeline(tmp_path):
     rgba = np.asarray(Image.open(tmp_path / "com" / "0000.png"))
     assert rgba.shape == (H, W, 4)
     assert np.abs(rgba[..., 3].astype(int) - ref_pha[0, ..., 0]).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_convert_video_pipelined_uint8_source_equals_float_source(dtype):
+    """The double-buffered upload / download path of convert_video (pinned staging, side streams): 7 frames in chunks of 3
+    (two full chunks and a short last one, so both buffer sets are reused), uint8 frames uploaded as bytes and divided by
+    255 on the device against the same frames as float tensors (ToTensor's values): identical bytes out; and chunked output
+    equals the oracle pipeline to one count."""
+    from robustvideomatting_amd import MattingNetwork
+    T, H, W = 7, 64, 96
+    clip = synthetic.make_clip(T, H, W, seed=6)[0]
+    u8 = O.frames_to_u8(clip).permute(0, 3, 1, 2).contiguous()            # [T,3,H,W] uint8, what a decoder yields
+    f32 = u8.float().div(255)                                             # ToTensor
+    params = synthetic.make_params("mobilenetv3", "deep_guided_filter", seed=1)
+    model = MattingNetwork("mobilenetv3").eval()
+    model.load_state_dict(params)
+    model = model.to("cuda", dtype)
+    outs = []
+    for src in (I.TensorSource(u8), I.TensorSource(f32), I.TensorSource(u8.clone()).pin()):
+        com, alpha = I.ListWriter(), I.ListWriter()
+        I.convert_video(model, src, downsample_ratio=0.5, output_type="video", output_composition=com, output_alpha=alpha,
+                        seq_chunk=3, progress=False)
+        one = I.ListWriter()
+        I.convert_video(model, src, downsample_ratio=0.5, output_type="video", output_composition=one, seq_chunk=3, progress=False)
+        assert len(com.frames) == T and len(alpha.frames) == T and len(one.frames) == T
+        outs.append((np.stack(com.frames), np.stack(alpha.frames), np.stack(one.frames)))
+    # what reaches the model is identical bit for bit (bytes divided by 255 on the device == ToTensor on the host) ...
+    pipe = I._Pipeline(torch.device("cuda", torch.cuda.current_device()))
+    for k in range(3):                                                    # both buffer sets, one reused
+        lo = 2 * k
+        a = pipe.upload(k, [u8[i] for i in range(lo, lo + 3)], dtype, True)
+        b = pipe.upload(k, [f32[i] for i in range(lo, lo + 3)], dtype, False)
+        torch.cuda.synchronize()
+        assert a.dtype == dtype and torch.equal(a, b) and torch.equal(b.cpu(), f32[lo:lo + 3].to(dtype))
+    # ... so the frames out are the same (fp32: bit for bit; 16-bit: a context that switches between its chunk plans takes a
+    # carried state at its 16-bit value or at the fp32 value it kept, depending on history - rounding-level, see rvm_mi355x.h)
+    for a, b in list(zip(outs[0], outs[1])) + list(zip(outs[0], outs[2])):      # float source, pinned source (no staging copy)
+        if dtype == torch.float32:
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert np.abs(outs[0][0].astype(int) - outs[0][2].astype(int)).max() <= 1   # two-output path vs the fused uint8 path
+    if dtype == torch.float32:
+        out = O.forward(params, f32.unsqueeze(0), downsample_ratio=0.5)
+        ref = O.frames_to_u8(O.compose_frames(out[0][0], out[1][0], "video")).numpy().astype(int)
+        assert np.abs(outs[0][0].astype(int) - ref).max() <= 1

@@ -210,6 +210,74 @@ def test_chunked_decoder_convs_forced(gc, monkeypatch, k):
     assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
 
 
+@pytest.mark.parametrize("tile", ["off", "4,4", "2,16", "8,4", "2,8", "4,8"])
+def test_fused_inverted_residual_blocks_forced_tiles(gc, monkeypatch, tile):
+    """mbconv_fused (features[2], [3], [7]..[10] as ONE launch each: expand -> depthwise -> project per tile of output
+    pixels) with every tile shape it offers forced in turn, and switched off (the two-launch form mbconv_ed + pw_gemm it
+    replaced, which stays the fallback for shapes the fused kernel does not fit): odd-sized maps (tiles hanging over every
+    border, stride-2 halos), a batch index, all three arithmetic modes, all taps."""
+    if tile == "off":
+        monkeypatch.setenv("RVM_MB_FUSE", "0")
+    else:
+        monkeypatch.setenv("RVM_MBF_TILE", tile)
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+    w = gc.run("fp32", H=150, W=201, ds=0.8, T=2, B=2, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=540, W=960, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    for k in ("f2", "f3", "f4"):
+        assert w[k] < 1e-4, w                       # the encoder taps behind the fused blocks stay fp32-accurate
+    w = gc.run("fp16fast", H=122, W=218, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
+
+
+def test_fused_blocks_launch_count():
+    """48 launches per mobilenetv3 frame with the fused blocks, 54 without."""
+    from robustvideomatting_amd import synthetic
+    m, _ = _setup(torch.float16)
+    src = synthetic.make_clip(1, 1080, 1920, seed=0)[:, 0].cuda().half()
+    with torch.no_grad():
+        m(src, downsample_ratio=0.25)
+    assert m.launch_count() <= 48
+
+
+def test_in_place_parameter_edits_are_picked_up():
+    """p.add_() bumps the version counter, p.data = ... changes the storage pointer: both re-pack the weights (checked on
+    every call here; every 64th under no_grad by default, documented in INTEGRATION.md)."""
+    m, _ = _setup(torch.float32)
+    m.edit_check_interval = 1
+    src = torch.rand(1, 3, 64, 96, device="cuda")
+    with torch.no_grad():
+        a = m(src, downsample_ratio=0.5)
+        m.project_mat.conv.bias.add_(0.05)
+        b = m(src, downsample_ratio=0.5)
+        assert (b[1] - a[1]).abs().max() > 1e-3
+        m.project_mat.conv.bias.data = m.project_mat.conv.bias.data - 0.05
+        c = m(src, downsample_ratio=0.5)
+    assert (c[1] - a[1]).abs().max() < 1e-6
+
+
+def test_plans_are_kept_reported_and_trimmed():
+    """rvm_memory_bytes / rvm_trim: the context reports what it holds (weights, the active plan's arena, parked plans) and
+    frees the parked plans on request; results are unchanged afterwards."""
+    m, _ = _setup(torch.float16)
+    a = torch.rand(1, 3, 128, 160, device="cuda").half()
+    b = torch.rand(1, 3, 96, 128, device="cuda").half()
+    with torch.no_grad():
+        ra = m(a, downsample_ratio=0.5)
+        mem1 = m._ctx.memory_bytes()
+        assert mem1["weights"] > 0 and mem1["active_plan"] > 0 and mem1["parked_plans"] == 0
+        m(b, downsample_ratio=0.5)
+        mem2 = m._ctx.memory_bytes()
+        assert mem2["parked_plans"] == mem1["active_plan"] and mem2["total"] == mem2["weights"] + mem2["active_plan"] + mem2["parked_plans"]
+        m._ctx.trim()
+        assert m._ctx.memory_bytes()["parked_plans"] == 0
+        ra2 = m(a, downsample_ratio=0.5)                  # re-planned from scratch
+    for x, y in zip(ra, ra2):
+        assert torch.equal(x, y)
+
+
 def test_fp32_1080p_at_ratio_one():
     """1920x1080 at downsample_ratio=1: the low-res map is the full frame, wider than any full-width LDS tile of the
     depthwise kernel (column tiles) - the largest shape the reference runs on common inputs."""
