@@ -167,6 +167,22 @@ struct ConvArgs {
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
+// ---- whole ConvGRU step in one launch (gru_fused.hip): gate conv, r * h, candidate conv, state blend -----------
+struct GruArgs {
+    const void* x; int xs;                  // the GRU's input: second half of the block's features [N][H*W][xs] (pointer at the half)
+    const void* h; int hmode;               // previous state [N][H*W][C] (0 fp32 / 1 fp16 / 2 bf16 elements) or null (zeros)
+    const void* wih; const float* bih;      // gate conv fragments [2 * ceil(C/16)][KS][512], tiles (r, z) interleaved; bias
+    const void* whh; const float* bhh;      // candidate conv fragments [ceil(C/16)][KS][512]; bias
+    void* hout; int omode;                  // new state [N][H*W][C]
+    void* hout2; int omode2;                // optional second copy (the caller's r_out in the 16-bit I/O modes)
+    int C, H, W, TH, TW, tiles_x, tiles_y;  // tiles of TH x TW pixels: 4 x 8, 8 x 8, 4 x 16 or 8 x 16
+};
+bool gru_fused_supported(int C, int es);
+size_t gru_fused_lds(int C, int TH, int TW, int es);
+template <typename T> void launch_gru_fused(const GruArgs& a, int N, hipStream_t s);
+template <typename T> int gru_fused_occupancy(int C, int TH, int TW);     // blocks per CU (needs the device)
+void gru_fused_init();
+
 // ---- resize / pyramid (+ encoder stem) ----------------------------------------------------------------------
 struct DownArgs {
     const void* src; void* s0; void* s1; void* s2; void* s3;
@@ -202,6 +218,7 @@ struct DgfApplyArgs {
     const void* src; const float* ab; void* fgr; void* pha;
     int H, W, h, w; float scale_y, scale_x;
     int ncols;                              // low-res columns one 2048-px row segment can touch (LDS tile)
+    int kx, rows;                           // dgf_apply_pick: 4 / 8 = the power-of-two kernel (W = kx w) with `rows` rows per block; 0 = general
     // fused driver output (rvm_forward_u8): composed uint8 [N][H][W][C] instead of fgr / pha; null: fgr / pha
     unsigned char* u8; int u8mode; float bgr[3];
 };
@@ -236,6 +253,8 @@ template <typename T> void launch_maxpool(const MaxPoolArgs& a, int N, hipStream
 template <typename T> void launch_down(const DownArgs& a, int N, int io, hipStream_t s);
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, int io, hipStream_t s);
+void dgf_apply_pick(DgfApplyArgs& a);                           // sets kx / rows from the geometry
+void dgf_apply_init();
 template <typename T> void launch_proj_out(const ProjOutArgs& a, int N, int io, hipStream_t s);
 template <typename T> size_t conv_lds_bytes(int MW, int NW, int KD, int S, int D, int CC, int SK);
 template <typename T> void launch_ed(const EdArgs& a, int N, int K, hipStream_t s);

@@ -252,3 +252,74 @@ __device__ __forceinline__ float act_f(float v, int act) {
     }
 }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---- tensors at the API boundary, 8 values at a time (dgf_apply, project_out, compose) ----------------------------------
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+template <typename TIO> struct IoV8;
+template <> struct IoV8<f16> {
+    typedef f16x8 type;
+    static __device__ __forceinline__ float get(const f16x8& v, int j) { return (float)v[j]; }
+    static __device__ __forceinline__ void set(f16x8& v, int j, f16 e) { v[j] = e; }
+};
+template <> struct IoV8<float> {
+    typedef f32x8 type;
+    static __device__ __forceinline__ float get(const f32x8& v, int j) { return v[j]; }
+    static __device__ __forceinline__ void set(f32x8& v, int j, float e) { v[j] = e; }
+};
+template <> struct IoV8<bf16> {
+    typedef u16x8 type;
+    static __device__ __forceinline__ float get(const u16x8& v, int j) { return (float)bf16_bits(v[j]); }
+    static __device__ __forceinline__ void set(u16x8& v, int j, bf16 e) { v[j] = e.v; }
+};
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 8 output values of one channel, packed to the I/O type pair by pair as they are produced
+template <typename TIO> struct Out8;
+template <> struct Out8<f16> {
+    unsigned r[4];
+    __device__ __forceinline__ void set(int jp, float a, float b) { f16x2 p = {(f16)a, (f16)b}; r[jp] = __builtin_bit_cast(unsigned, p); }
+    __device__ __forceinline__ void store(f16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
+    __device__ __forceinline__ f16 get(int j) const { return __builtin_bit_cast(f16x2, r[j >> 1])[j & 1]; }
+};
+template <> struct Out8<bf16> {
+    unsigned r[4];
+    __device__ __forceinline__ void set(int jp, float a, float b) { r[jp] = (unsigned)bf16(a).v | ((unsigned)bf16(b).v << 16); }
+    __device__ __forceinline__ void store(bf16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
+    __device__ __forceinline__ bf16 get(int j) const { return bf16_bits((unsigned short)(r[j >> 1] >> (16 * (j & 1)))); }
+};
+template <> struct Out8<float> {
+    float r[8];
+    __device__ __forceinline__ void set(int jp, float a, float b) { r[2 * jp] = a; r[2 * jp + 1] = b; }
+    __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = f32x4{r[0], r[1], r[2], r[3]}; *(f32x4*)(p + 4) = f32x4{r[4], r[5], r[6], r[7]}; }
+    __device__ __forceinline__ float get(int j) const { return r[j]; }
+};
+// Output step of the reference driver (inference.py:116,137-141; inference_utils.py:44), one pixel: every tensor op of the
+// reference rounds to the tensor dtype, so the arithmetic is written in that type (TIO) op by op and the bytes come out
+// identical.  Used by compose_u8 (its own pass over fgr / pha) and by dgf_apply's fused uint8 output.
+template <typename TIO> __device__ __forceinline__ unsigned char to_byte(TIO v) {
+    const TIO m = v * (TIO)255.0f;                                   // .mul(255) in the tensor dtype
+    return (unsigned char)(int)(float)m;                            // .byte(): truncation (values are in [0, 255])
+}
+template <typename TIO>
+__device__ __forceinline__ unsigned compose_px(int mode, TIO f0, TIO f1, TIO f2, TIO al, const float* bgr) {
+    if (mode == COMPOSE_ALPHA) { const unsigned b = to_byte<TIO>(al); return b | (b << 8) | (b << 16); }
+    const TIO one = (TIO)1.0f, zero = (TIO)0.0f;
+    TIO f[3] = {f0, f1, f2};
+    unsigned out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        TIO v = f[c];
+        if (mode == COMPOSE_GREEN) {
+#pragma clang fp contract(off)                                       // no fma: the reference rounds after every op
+            const TIO t1 = v * al;                                   // each op rounds to TIO like the torch ops do
+            const TIO t2 = one - al;
+            const TIO t3 = (TIO)bgr[c] * t2;
+            v = t1 + t3;
+        } else if (mode == COMPOSE_RGBA) {
+            v = v * (al > zero ? one : zero);
+        }
+        out |= (unsigned)to_byte<TIO>(v) << (8 * c);
+    }
+    if (mode == COMPOSE_RGBA) out |= (unsigned)to_byte<TIO>(al) << 24;
+    return out;
+}

@@ -1314,18 +1314,68 @@ int build_plan(rvm_ctx* c) {
     auto gru = [&](const std::string& name, const GruLayer& G, const T* xb, int xs, int Hh, int Ww, int ridx) -> int {
         const int C = G.C;
         const size_t per = (size_t)Bs * Hh * Ww;    // pixels of one time step
-        T* rh = abuf(per * C);
-        float* z = fbuf(per * C);
         // io16: fp32 states in the arena for every step (allocated above); else for chunks only, in the state's type
         char* hs = io16 ? (char*)hseq32[ridx] : (TT > 1 ? (char*)c->arena_alloc((size_t)TT * per * C * ses) : nullptr);
         hseq[ridx] = hs;
         const float* hin = hin32[ridx];
+        // ---- the two large-map GRUs (decode1, decode2): the whole step in one launch (gru_fused.hip)
+        int fusedTH = 0, fusedTW = 0;
+        if (gru_fused_supported(C, (int)es) && G.ih.nchunks == 1 && G.hh.nchunks == 1 && G.ih.Cpad == 2 * C && G.hh.Cpad == 2 * C &&
+            G.ih.NT == 2 * cdiv(C, 16) && G.hh.NT == cdiv(C, 16) && !(getenv("RVM_GRU_FUSE") && atoi(getenv("RVM_GRU_FUSE")) == 0)) {
+            // Tile candidates.  Small tiles recompute more of the gate conv's one-pixel ring ((TH + 2)(TW + 2) / (TH TW): 1.9x at
+            // 4 x 8, 1.4x at 8 x 16) but one frame has too few large tiles for 256 CUs; many frames: large tiles, measured at
+            // plan time where the plan is tuned.
+            static const int cand[4][2] = {{4, 8}, {8, 8}, {4, 16}, {8, 16}};
+            int model = 0; double best = 1e30;
+            for (int k = 0; k < 4; ++k) {
+                const int th = cand[k][0], tw = cand[k][1], blocks = cdiv(Hh, th) * cdiv(Ww, tw) * Bs;
+                if (gru_fused_lds(C, th, tw, (int)es) > 160 * 1024) continue;
+                const int wp1 = 8 / G.ih.NT, wp2 = 8 / G.hh.NT, mt1 = cdiv((th + 2) * (tw + 2), 16), mt2 = th * tw / 16;
+                // MFMA cycles of a block per SIMD (two of its waves each: all m-tiles over a slice of K) + the phases that do not
+                // overlap inside one block
+                const double mf = 2.0 * (mt1 * cdiv(G.ih.KS, wp1) + mt2 * cdiv(G.hh.KS, wp2)) * 16.0 * (split ? 3 : 1);
+                int occ = 1;
+                if constexpr (std::is_same<T, float>::value) occ = split ? gru_fused_occupancy<f32s>(C, th, tw) : gru_fused_occupancy<float>(C, th, tw);
+                else occ = gru_fused_occupancy<T>(C, th, tw);
+                occ = std::min(occ, 2);
+                const double cost = (double)cdiv(blocks, 256 * occ) * (occ * mf + 3000.0);
+                if (cost < best - 1e-9) { best = cost; model = k; }
+            }
+            int pick = tune_pick(name + ".fused", 4, model);
+            if (const char* e = getenv("RVM_GRU_TILE")) {                   // test hook: "rows,cols"
+                int th = 0, tw = 0;
+                if (sscanf(e, "%d,%d", &th, &tw) == 2)
+                    for (int k = 0; k < 4; ++k) if (cand[k][0] == th && cand[k][1] == tw) pick = k;
+            }
+            fusedTH = cand[pick][0]; fusedTW = cand[pick][1];
+            if (getenv("RVM_VERBOSE") && c->arena)
+                fprintf(stderr, "[rvm] %s.fused tile %dx%d blocks %d\n", name.c_str(), fusedTH, fusedTW, cdiv(Hh, fusedTH) * cdiv(Ww, fusedTW) * Bs);
+        }
+        T* rh = fusedTH ? nullptr : abuf(per * C);
+        float* z = fusedTH ? nullptr : fbuf(per * C);
         for (int t = 0; t < TT; ++t) {
             const std::string nm = TT > 1 ? name + "[" + std::to_string(t) + "]" : name;
             const T* xt = xb + (size_t)t * per * xs;
             const void* hp = t ? hs + (size_t)(t - 1) * per * C * ses : nullptr;      // nullptr: the state coming in
             void* ho = hs ? hs + (size_t)t * per * C * ses : nullptr;                 // nullptr: the caller's r_out
             const bool last = t == TT - 1;
+            if (fusedTH) {
+                GruArgs a; memset(&a, 0, sizeof a);
+                a.x = xt; a.xs = xs; a.hmode = es == 2 ? 1 : 0; a.omode = a.hmode; a.omode2 = io16 ? io16 : a.hmode;
+                a.wih = wb + G.ih.w; a.bih = (const float*)(wb + G.ih.bias); a.whh = wb + G.hh.w; a.bhh = (const float*)(wb + G.hh.bias);
+                a.C = C; a.H = Hh; a.W = Ww; a.TH = fusedTH; a.TW = fusedTW; a.tiles_x = cdiv(Ww, fusedTW); a.tiles_y = cdiv(Hh, fusedTH);
+                const double px = (double)per;
+                add(nm + ".fused", 2.0 * px * 9.0 * 2 * C * 3 * C, px * C * 3.0 * es + (double)(G.ih.KS * G.ih.NT + G.hh.KS * G.hh.NT) * 512 * es,
+                    [=](hipStream_t st, const FrameIO& io) {
+                        GruArgs b = a;
+                        b.h = t ? hp : (io16 ? (const void*)hin : io.r_in[ridx]);
+                        b.hout = ho ? ho : io.r_out[ridx];
+                        b.hout2 = (ho && last) ? io.r_out[ridx] : nullptr;            // the state handed back
+                        if constexpr (std::is_same<T, float>::value) { if (split) { launch_gru_fused<f32s>(b, Bs, st); return; } }
+                        launch_gru_fused<T>(b, Bs, st);
+                    });
+                continue;
+            }
             if (conv3(nm + ".ih", G.ih, Hh, Ww, Hh, Ww, EPI_GRU_IH, [=](ConvArgs& a, const FrameIO& io) {
                     const void* h = t ? hp : (io16 ? (const void*)hin : io.r_in[ridx]);
                     a.src[0] = ConvSrc{xt, C, xs, 0, 0, 0, 0}; a.src[1] = ConvSrc{h, C, C, 0, 0, 0, 0}; a.nsrc = 2;
@@ -1407,7 +1457,8 @@ int build_plan(rvm_ctx* c) {
         }
         DgfApplyArgs ap; memset(&ap, 0, sizeof ap); ap.ab = ab; ap.H = c->H; ap.W = c->W; ap.h = c->h; ap.w = c->w;
         ap.scale_y = (float)c->h / (float)c->H; ap.scale_x = (float)c->w / (float)c->W;
-        ap.ncols = std::min(c->w, (int)std::ceil(2048.0 * ap.scale_x) + 3);
+        ap.ncols = std::min(c->w, (int)std::ceil(std::min(2048, c->W) * (double)ap.scale_x) + 3);
+        dgf_apply_pick(ap);
         ProjOutArgs po; po.hid = hid; po.wt = dw; po.H = c->h; po.W = c->w;
         const bool refine = c->ds != 1.0;
         const double lowpx = (double)B * c->h * c->w, fullpx = (double)B * c->H * c->W;

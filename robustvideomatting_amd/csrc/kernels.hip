@@ -2369,223 +2369,6 @@ template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_
 template void launch_dgf_low<f16>(const DgfLowArgs&, int, hipStream_t);
 template void launch_dgf_low<float>(const DgfLowArgs&, int, hipStream_t);
 
-// ------------------------------------------------------------------------------------------
-// Refiner, full-res half: bilinear-upsample A|b (size-driven coords, deep_guided_filter.py:
-// 37-39), out = A*[src,gray]+b (:41), fgr = clamp(out+src), pha = clamp(out) (model.py:65-67).
-// One pass: src read once, fgr/pha written once; a thread owns 8 consecutive x.
-// ------------------------------------------------------------------------------------------
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-template <typename TIO> struct IoV8;
-template <> struct IoV8<f16> {
-    typedef f16x8 type;
-    static __device__ __forceinline__ float get(const f16x8& v, int j) { return (float)v[j]; }
-    static __device__ __forceinline__ void set(f16x8& v, int j, f16 e) { v[j] = e; }
-};
-template <> struct IoV8<float> {
-    typedef f32x8 type;
-    static __device__ __forceinline__ float get(const f32x8& v, int j) { return v[j]; }
-    static __device__ __forceinline__ void set(f32x8& v, int j, float e) { v[j] = e; }
-};
-template <> struct IoV8<bf16> {
-    typedef u16x8 type;
-    static __device__ __forceinline__ float get(const u16x8& v, int j) { return (float)bf16_bits(v[j]); }
-    static __device__ __forceinline__ void set(u16x8& v, int j, bf16 e) { v[j] = e.v; }
-};
-typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// 8 output values of one channel, packed to the I/O type pair by pair as they are produced
-template <typename TIO> struct Out8;
-template <> struct Out8<f16> {
-    unsigned r[4];
-    __device__ __forceinline__ void set(int jp, float a, float b) { f16x2 p = {(f16)a, (f16)b}; r[jp] = __builtin_bit_cast(unsigned, p); }
-    __device__ __forceinline__ void store(f16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
-    __device__ __forceinline__ f16 get(int j) const { return __builtin_bit_cast(f16x2, r[j >> 1])[j & 1]; }
-};
-template <> struct Out8<bf16> {
-    unsigned r[4];
-    __device__ __forceinline__ void set(int jp, float a, float b) { r[jp] = (unsigned)bf16(a).v | ((unsigned)bf16(b).v << 16); }
-    __device__ __forceinline__ void store(bf16* p) const { *(u32x4*)p = u32x4{r[0], r[1], r[2], r[3]}; }
-    __device__ __forceinline__ bf16 get(int j) const { return bf16_bits((unsigned short)(r[j >> 1] >> (16 * (j & 1)))); }
-};
-template <> struct Out8<float> {
-    float r[8];
-    __device__ __forceinline__ void set(int jp, float a, float b) { r[2 * jp] = a; r[2 * jp + 1] = b; }
-    __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = f32x4{r[0], r[1], r[2], r[3]}; *(f32x4*)(p + 4) = f32x4{r[4], r[5], r[6], r[7]}; }
-    __device__ __forceinline__ float get(int j) const { return r[j]; }
-};
-// Output step of the reference driver (inference.py:116,137-141; inference_utils.py:44), one pixel: every tensor op of the
-// reference rounds to the tensor dtype, so the arithmetic is written in that type (TIO) op by op and the bytes come out
-// identical.  Used by compose_u8 (its own pass over fgr / pha) and by dgf_apply's fused uint8 output.
-template <typename TIO> __device__ __forceinline__ unsigned char to_byte(TIO v) {
-    const TIO m = v * (TIO)255.0f;                                   // .mul(255) in the tensor dtype
-    return (unsigned char)(int)(float)m;                            // .byte(): truncation (values are in [0, 255])
-}
-template <typename TIO>
-__device__ __forceinline__ unsigned compose_px(int mode, TIO f0, TIO f1, TIO f2, TIO al, const float* bgr) {
-    if (mode == COMPOSE_ALPHA) { const unsigned b = to_byte<TIO>(al); return b | (b << 8) | (b << 16); }
-    const TIO one = (TIO)1.0f, zero = (TIO)0.0f;
-    TIO f[3] = {f0, f1, f2};
-    unsigned out = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        TIO v = f[c];
-        if (mode == COMPOSE_GREEN) {
-#pragma clang fp contract(off)                                       // no fma: the reference rounds after every op
-            const TIO t1 = v * al;                                   // each op rounds to TIO like the torch ops do
-            const TIO t2 = one - al;
-            const TIO t3 = (TIO)bgr[c] * t2;
-            v = t1 + t3;
-        } else if (mode == COMPOSE_RGBA) {
-            v = v * (al > zero ? one : zero);
-        }
-        out |= (unsigned)to_byte<TIO>(v) << (8 * c);
-    }
-    if (mode == COMPOSE_RGBA) out |= (unsigned)to_byte<TIO>(al) << 24;
-    return out;
-}
-// Block = one segment of 2048 consecutive x of one row (256 threads x 8 px).  The A|b rows are first
-// interpolated vertically for the low-res columns the segment touches and parked in LDS
-// ([column][8] fp32), then every thread interpolates horizontally out of LDS, branch-free, and packs
-// its results to the I/O type pair by pair (few registers -> many rows in flight per CU).
-template <typename TIO>
-__global__ __launch_bounds__(256, 6) void dgf_apply(DgfApplyArgs a) {      // <= 85 VGPRs: 6 rows in flight per CU
-    [[maybe_unused]] Stamper stamp;
-    typedef typename IoV8<TIO>::type V8;
-    extern __shared__ __attribute__((aligned(16))) f32x4 colAB[];       // [ncols][2]
-    const int tid = threadIdx.x;
-    const int seg0 = blockIdx.x * 2048;
-    const int x0 = seg0 + tid * 8;
-    const int y = blockIdx.y, n = blockIdx.z;
-    const size_t plane = (size_t)a.H * a.W;
-    const TIO* sp = (const TIO*)a.src + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    const bool active = x0 < a.W;
-    const bool full = (x0 + 8 <= a.W) && ((a.W & 7) == 0);
-    V8 s[3];
-    if (full) {                                                         // issued first: in flight during the LDS phase
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s[c] = *(const V8*)(sp + c * plane);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                TIO e = (TIO)0.f;
-                if (active && x0 + j < a.W) e = sp[c * plane + j];
-                IoV8<TIO>::set(s[c], j, e);
-            }
-    }
-    // ---- vertical interpolation of the columns this segment needs
-    float sy = a.scale_y * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    int iy0 = (int)sy; if (iy0 > a.h - 1) iy0 = a.h - 1;
-    const int iy1 = iy0 + (iy0 < a.h - 1);
-    const float ly = sy - iy0;
-    float sxb = a.scale_x * (seg0 + 0.5f) - 0.5f; if (sxb < 0.f) sxb = 0.f;
-    const int cbase = min((int)sxb, a.w - 1);
-    const f32x4* r0 = (const f32x4*)(a.ab + ((size_t)n * a.h + iy0) * a.w * 8);
-    const f32x4* r1 = (const f32x4*)(a.ab + ((size_t)n * a.h + iy1) * a.w * 8);
-    // item = (column, A or b half); the first 5 x 256 items (all of them up to a 0.31 ratio) are requested
-    // together - one round trip to L2 instead of one per 256 items
-    {
-        constexpr int SU = 5;
-        f32x4 t[SU], u[SU];
-#pragma unroll
-        for (int k = 0; k < SU; ++k) {
-            const int i = tid + 256 * k;
-            if (256 * k < 2 * a.ncols) {                                // uniform
-                const int col = min(cbase + (i >> 1), a.w - 1);
-                t[k] = r0[col * 2 + (i & 1)]; u[k] = r1[col * 2 + (i & 1)];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < SU; ++k) {
-            const int i = tid + 256 * k;
-            if (i < 2 * a.ncols) colAB[i] = (1.f - ly) * t[k] + ly * u[k];
-        }
-        for (int i = tid + 256 * SU; i < 2 * a.ncols; i += 256) {
-            const int col = min(cbase + (i >> 1), a.w - 1);
-            const f32x4 tt = r0[col * 2 + (i & 1)], uu = r1[col * 2 + (i & 1)];
-            colAB[i] = (1.f - ly) * tt + ly * uu;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    Out8<TIO> of[3], op;
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-        float o[2][4];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int j = 2 * jp + e;
-            float sx = a.scale_x * (x0 + j + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-            int ix0 = (int)sx; if (ix0 > a.w - 1) ix0 = a.w - 1;
-            const int ix1 = ix0 + (ix0 < a.w - 1);
-            const float lx = sx - ix0;
-            const int k0 = min(ix0 - cbase, a.ncols - 1), k1 = min(ix1 - cbase, a.ncols - 1);
-            const f32x4 A = (1.f - lx) * colAB[2 * k0] + lx * colAB[2 * k1];
-            const f32x4 B = (1.f - lx) * colAB[2 * k0 + 1] + lx * colAB[2 * k1 + 1];
-            const float sr = IoV8<TIO>::get(s[0], j), sg = IoV8<TIO>::get(s[1], j), sb = IoV8<TIO>::get(s[2], j);
-            const float gray = (sr + sg + sb) / 3.f;
-            o[e][0] = fminf(fmaxf(A[0] * sr + B[0] + sr, 0.f), 1.f);
-            o[e][1] = fminf(fmaxf(A[1] * sg + B[1] + sg, 0.f), 1.f);
-            o[e][2] = fminf(fmaxf(A[2] * sb + B[2] + sb, 0.f), 1.f);
-            o[e][3] = fminf(fmaxf(A[3] * gray + B[3], 0.f), 1.f);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) of[c].set(jp, o[0][c], o[1][c]);
-        op.set(jp, o[0][3], o[1][3]);
-    }
-    if (a.u8) {
-        // fused driver output: composed uint8 NHWC instead of fgr / pha (the values are first rounded to TIO exactly as
-        // the fgr / pha tensors would hold them)
-        unsigned px[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) px[j] = compose_px<TIO>(a.u8mode, of[0].get(j), of[1].get(j), of[2].get(j), op.get(j), a.bgr);
-        const size_t p0 = (size_t)n * plane + (size_t)y * a.W + x0;
-        if (a.u8mode == COMPOSE_RGBA) {
-            unsigned* o = (unsigned*)(a.u8 + p0 * 4);
-            if (full) { *(u32x4*)o = u32x4{px[0], px[1], px[2], px[3]}; *(u32x4*)(o + 4) = u32x4{px[4], px[5], px[6], px[7]}; }
-            else for (int j = 0; j < 8; ++j) if (x0 + j < a.W) o[j] = px[j];
-        } else if (full) {
-            // 8 px x 3 bytes = 24 bytes at an 8-byte aligned address (x0 % 8 == 0, W % 8 == 0)
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            u32x2* o = (u32x2*)(a.u8 + p0 * 3);
-            const unsigned w0 = (px[0] & 0xFFFFFF) | (px[1] << 24), w1 = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
-            const unsigned w2 = ((px[2] >> 16) & 0xFF) | (px[3] << 8), w3 = (px[4] & 0xFFFFFF) | (px[5] << 24);
-            const unsigned w4 = ((px[5] >> 8) & 0xFFFF) | (px[6] << 16), w5 = ((px[6] >> 16) & 0xFF) | (px[7] << 8);
-            o[0] = u32x2{w0, w1}; o[1] = u32x2{w2, w3}; o[2] = u32x2{w4, w5};
-        } else {
-            unsigned char* o = a.u8 + p0 * 3;
-            for (int j = 0; j < 8; ++j)
-                if (x0 + j < a.W) { o[3 * j] = px[j] & 0xFF; o[3 * j + 1] = (px[j] >> 8) & 0xFF; o[3 * j + 2] = (px[j] >> 16) & 0xFF; }
-        }
-        return;
-    }
-    TIO* fp = (TIO*)a.fgr + (size_t)n * 3 * plane + (size_t)y * a.W + x0;
-    TIO* pp = (TIO*)a.pha + (size_t)n * plane + (size_t)y * a.W + x0;
-    if (full) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) of[c].store(fp + c * plane);
-        op.store(pp);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (x0 + j < a.W) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) fp[c * plane + j] = of[c].get(j);
-                pp[j] = op.get(j);
-            }
-        }
-    }
-}
-template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, int io, hipStream_t s) {
-    const dim3 grid((a.W + 2047) / 2048, a.H, N);
-    const size_t lds = (size_t)a.ncols * 32;
-    if (sizeof(T) == 2 || io == IO_F16) hipLaunchKernelGGL((dgf_apply<f16>), grid, dim3(256), lds, s, a);
-    else if (io == IO_BF16) hipLaunchKernelGGL((dgf_apply<bf16>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dgf_apply<float>), grid, dim3(256), lds, s, a);
-}
-template void launch_dgf_apply<f16>(const DgfApplyArgs&, int, int, hipStream_t);
-template void launch_dgf_apply<float>(const DgfApplyArgs&, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // downsample_ratio == 1 tail (no refiner): project_mat + residual + clamp (model.py:62,65-67)
@@ -2844,6 +2627,8 @@ template <typename T> static void conv_attr_all() {
 }
 void kernels_init() {
     mbf_init();
+    gru_fused_init();
+    dgf_apply_init();
     conv_attr_all<f16>(); conv_attr_all<float>(); conv_attr_all<f32s>();
     (void)hipFuncSetAttribute((const void*)pw_gemm_lds<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<1>());
     (void)hipFuncSetAttribute((const void*)pw_gemm_lds<f32s, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwl_lds_bytes<1>());
@@ -2852,9 +2637,6 @@ void kernels_init() {
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<f16, f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f16>());
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, f32s>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<f32s>());
     (void)hipFuncSetAttribute((const void*)dgf_lowres_mfma<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dgf_lds_bytes<float>());
-    (void)hipFuncSetAttribute((const void*)dgf_apply<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)dgf_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)dgf_apply<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 #define RVM_ED_ATTR1(TT, KK, KS_) \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)mbconv_ed<TT, KK, KS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2872,4 +2654,6 @@ void kernels_init() {
 
 #ifdef RVM_STAMPS
 #include "mbconv_fused.hip"   // the stamps build is one translation unit (device_common.hpp)
+#include "gru_fused.hip"
+#include "dgf_apply.hip"
 #endif

@@ -232,14 +232,82 @@ def test_fused_inverted_residual_blocks_forced_tiles(gc, monkeypatch, tile):
     assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
 
 
+@pytest.mark.parametrize("tile", ["off", "4,8", "8,8", "4,16", "8,16"])
+def test_fused_convgru_forced_tiles(gc, monkeypatch, tile):
+    """gru_fused (decode1 / decode2: gate conv, r * h, candidate conv and the state blend as ONE launch per time step) with
+    each of its tile shapes forced, and switched off (the conv_kxk ih + hh pair it replaced, which the two small-map GRUs
+    still use): odd-sized maps (tiles hanging over every border), a batch index, chunks of T > 1 (the state of step t - 1
+    read back from the arena), zero and given initial states, all arithmetic modes, every tap including r1..r4."""
+    if tile == "off":
+        monkeypatch.setenv("RVM_GRU_FUSE", "0")
+    else:
+        monkeypatch.setenv("RVM_GRU_TILE", tile)
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+    w = gc.run("fp32", H=150, W=201, ds=0.8, T=3, B=2, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=540, W=960, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    for k in ("x1", "x2"):
+        assert w[k] < 1e-4, w                       # the decoder features behind the fused GRUs stay fp32-accurate
+    w = gc.run("bf16", H=122, W=218, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < 8e-3 and w["pha"] < 8e-3, w
+    w = gc.run("fp16fast", H=122, W=218, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
+    # a chunk in one native call (states of step t - 1 read back from the arena, the caller's copy written by the last
+    # step) against the same frames fed one by one
+    from robustvideomatting_amd import synthetic
+    for tdt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+        m, _ = _setup(tdt)
+        clip = synthetic.make_clip(3, 90, 134, seed=5, B=2).cuda().to(tdt)
+        with torch.no_grad():
+            a = m(clip, None, None, None, None, None, 0.6)
+            rec = [None] * 4
+            for s in range(3):
+                o = m(clip[:, s], None, *rec, 0.6)
+                rec = o[2:]
+                assert (o[0].float() - a[0][:, s].float()).abs().max() < tol and (o[1].float() - a[1][:, s].float()).abs().max() < tol
+        for x, y in zip(rec, a[2:]):
+            assert (x.float() - y.float()).abs().max() < tol
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.float32, torch.bfloat16])
+def test_dgf_apply_power_of_two_kernel_is_bit_identical_to_the_general_one(monkeypatch, tdt):
+    """dgf_apply_pow2 (ratios 1/4 and 1/8 with W % 8 == 0: a thread's 8 pixels on 4 / 3 fixed low-res columns with compile-time
+    fractions, 1 or 2 rows per block) against the general kernel (RVM_DGF_POW2=0) on the same plan: every fgr / pha bit equal -
+    HD and 4K, two segments per row (W > 2048), the smallest map, a batch index; a ratio the special kernel does not take
+    (W % 4 != 0) runs the general kernel either way."""
+    from robustvideomatting_amd import synthetic
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+
+    def run(H, W, ds, B, pow2, rows=None):
+        monkeypatch.setenv("RVM_DGF_POW2", "1" if pow2 else "0")
+        if rows is None:
+            monkeypatch.delenv("RVM_DGF_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("RVM_DGF_ROWS", str(rows))
+        m, _ = _setup(tdt)
+        src = synthetic.make_clip(1, H, W, seed=1, B=B)[:, 0].to("cuda", tdt)
+        with torch.no_grad():
+            o = m(src, downsample_ratio=ds)
+        return o[0].clone(), o[1].clone()
+
+    for H, W, ds, B in ((1080, 1920, 0.25, 2), (2160, 3840, 0.125, 1), (64, 4096, 0.25, 1), (48, 4104, 0.125, 1), (8, 8, 0.25, 3),
+                        (270, 479, 0.25, 1)):
+        base = run(H, W, ds, B, False)
+        for rows in (None, 1):
+            got = run(H, W, ds, B, True, rows)
+            assert torch.equal(base[0], got[0]) and torch.equal(base[1], got[1]), (H, W, ds, B, rows)
+
+
 def test_fused_blocks_launch_count():
-    """48 launches per mobilenetv3 frame with the fused blocks, 54 without."""
+    """46 launches per mobilenetv3 frame with the fused blocks and GRUs, 54 without."""
     from robustvideomatting_amd import synthetic
     m, _ = _setup(torch.float16)
     src = synthetic.make_clip(1, 1080, 1920, seed=0)[:, 0].cuda().half()
     with torch.no_grad():
         m(src, downsample_ratio=0.25)
-    assert m.launch_count() <= 48
+    assert m.launch_count() <= 46
 
 
 def test_in_place_parameter_edits_are_picked_up():
