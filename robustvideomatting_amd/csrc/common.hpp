@@ -167,6 +167,13 @@ struct ConvArgs {
     int dbg;                                // ablation switches for timing experiments (RVM_DBG env), 0 in production
 };
 
+// ---- decoder cat-convs with the weights in registers (conv_cat.hip); variant = tile * 3 + wave layout (see there)
+constexpr int CCAT_NVAR = 12;
+bool conv_cat_supported(const ConvArgs& a, int variant, int es, size_t* lds_out);
+void conv_cat_shape(const ConvArgs& a, int variant, int* th, int* tw, int* ntb, int* ksp, int* mtw);
+template <typename T> void launch_conv_cat(const ConvArgs& a, int N, int variant, hipStream_t s);
+void conv_cat_init();
+
 // ---- whole ConvGRU step in one launch (gru_fused.hip): gate conv, r * h, candidate conv, state blend -----------
 struct GruArgs {
     const void* x; int xs;                  // the GRU's input: second half of the block's features [N][H*W][xs] (pointer at the half)

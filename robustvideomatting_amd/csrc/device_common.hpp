@@ -242,6 +242,20 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[MW][NW], const Frag<T> (&w
         for (int ni = 0; ni < NW; ++ni) mma(acc[mi][ni], w[ni], x[mi]);
 }
 
+// N independent accumulators against one weight fragment; the split type's three terms go term by term so that no MFMA
+// waits for its predecessor
+template <int N> __device__ __forceinline__ void mma_n(f32x4* acc, const Frag<f32s>& w, const Frag<f32s>* x) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.lo, x[i].hi, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x[i].lo, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x[i].hi, acc[i], 0, 0, 0);
+}
+template <int N, typename T> __device__ __forceinline__ void mma_n(f32x4* acc, const Frag<T>& w, const Frag<T>* x) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) mma(acc[i], w, x[i]);
+}
 __device__ __forceinline__ float act_f(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);

@@ -875,6 +875,16 @@ int build_plan(rvm_ctx* c) {
         }
         const Conv3Layer& L = *Lp;
         const int B = nb ? nb : Bs * TT;                    // samples of this launch (a GRU step: Bs)
+        // conv_cat (weights in registers, K split over the waves): extra candidates after the others for the decoder's
+        // conv + BN + ReLU layers whose K fits the wave slices
+        int nreg = 0, reg_var[CCAT_NVAR];
+        ConvArgs p0; memset(&p0, 0, sizeof p0);
+        if (epi == EPI_RELU && L0.geo == 0 && L0.nchunks == 1 && !keep && !(getenv("RVM_CONV_REG") && atoi(getenv("RVM_CONV_REG")) == 0)) {
+            p0.Cpad = L0.Cpad; p0.KS = L0.KS; p0.NT = L0.NT; p0.CC = L0.CC; p0.nchunks = 1; p0.epi = epi; p0.Cout = L0.Cout;
+            FrameIO none; memset(&none, 0, sizeof none);
+            fill(p0, none);
+            for (int v = 0; v < CCAT_NVAR; ++v) if (conv_cat_supported(p0, v, (int)es, nullptr)) reg_var[nreg++] = v;
+        }
         ConvArgs a; memset(&a, 0, sizeof a);
         a.Cpad = L.Cpad; a.w = wb + L.w; a.KS = L.KS; a.NT = L.NT; a.bias = (const float*)(wb + L.bias);
         a.H = Ho; a.W = Wo; a.Hi = Hi; a.Wi = Wi; a.tiles_x = cdiv(Wo, 16); a.epi = epi; a.Cout = L.Cout;
@@ -922,11 +932,53 @@ int build_plan(rvm_ctx* c) {
             }
             if (nvalid == 0) return fail("conv: input patch does not fit LDS");
             if (alt_ok && nvalid != alt_first) return fail("conv: candidate lists of the two packings disagree");
-            const int pick = valid[tune_pick(name, nvalid + (alt_ok ? NALT : 0), model)];      // (an alt index never reaches here: Lp == alt then)
+            const int reg_first = nvalid + (alt_ok ? NALT : 0);
+            for (int r = 0; r < nreg; ++r) {
+                // a block: launch + staging of its patch, then its waves' slice of K over their m-tiles (two waves per SIMD,
+                // 16 cycles per MFMA at ~2.1 GHz), then the slices' sum
+                int th, tw, ntb, ksp, mtw;
+                conv_cat_shape(p0, reg_var[r], &th, &tw, &ntb, &ksp, &mtw);
+                const int blocks = cdiv(Ho, th) * cdiv(Wo, tw) * cdiv(L.NT, ntb) * B;
+                size_t ldsb = 0;
+                conv_cat_supported(p0, reg_var[r], (int)es, &ldsb);
+                const int per_cu = (ldsb > 80 * 1024 || ksp > 5 || th * tw == 256) ? 1 : 2, nper = cdiv(blocks, 256);
+                // fitted to the in-kernel timelines of the four HD-frame layers: launch, staging (patch pixels x channels),
+                // the wave's MFMAs (two waves per SIMD, three per step on the split type), the slices' sum and the store
+                const int mt = th * tw / 16;
+                const double blk = 1.6 + 2.5 + 1e-4 * (th + 2) * (tw + 2) * L.CC + 0.9 + 0.015 * (split ? 3 : 1) * ksp * mtw + 0.6 + 1.0 * cdiv(mt * ntb, 8);
+                const double cost = blk * (per_cu == 2 && nper > 1 ? 0.75 * nper : nper) * 0.62;     // (0.62: on the scale of the conv_kxk model above, which reads low)
+                if (cost < best - 1e-9) { best = cost; model = reg_first + r; }
+            }
+            int pidx = tune_pick(name, reg_first + nreg, model, nreg > 0);       // with conv_cat in the list: always measured at plan time
+            if (const char* e = getenv("RVM_CONV_REG_VAR")) {        // test hook: force that conv_cat variant where it applies
+                for (int r = 0; r < nreg; ++r) if (reg_var[r] == atoi(e)) pidx = reg_first + r;
+            }
+            if (pidx >= reg_first) {
+                const int tile = reg_var[pidx - reg_first];
+                if (getenv("RVM_VERBOSE") && c->arena) fprintf(stderr, "[rvm] %-16s conv_cat variant %d (tile %d, layout %d) KS %d NT %d\n", name.c_str(), tile, tile / 3, tile % 3, L.KS, L.NT);
+                auto fn = [=](hipStream_t st, const FrameIO& io) {
+                    ConvArgs b = a; fill(b, io);
+                    if constexpr (std::is_same<T, float>::value) { if (split) { launch_conv_cat<f32s>(b, B, tile, st); return; } }
+                    launch_conv_cat<T>(b, B, tile, st);
+                };
+                double px_bytes = 0;
+                {
+                    ConvArgs probe = a; FrameIO none; memset(&none, 0, sizeof none);
+                    fill(probe, none);
+                    for (int k = 0; k < probe.nsrc; ++k) {
+                        const ConvSrc& S = probe.src[k];
+                        px_bytes += (double)(S.up ? S.Hs * S.Ws : Hi * Wi) * S.C * (S.f16 ? 2 : es);
+                    }
+                    px_bytes += (double)Ho * Wo * L.Cout * es;
+                }
+                add(name, 2.0 * B * Ho * Wo * 9.0 * L.Cin * L.Cout, (double)B * px_bytes + 9.0 * L.Cin * L.Cout * es, fn);
+                return 0;
+            }
+            const int pick = valid[pidx];      // (an alt index never reaches here: Lp == alt then)
             MW = cand[pick][0]; NW = cand[pick][1];
         } else if (Lp == alt && alt_ok) {
             // the chunked packing, one block per tile looping over the chunks
-            int k = tune_pick(name, alt_first + NALT, 0) - alt_first;
+            int k = tune_pick(name, alt_first + NALT + nreg, 0, nreg > 0) - alt_first;
             if (alt_force >= 0) k = alt_force;
             if (k < 0 || k >= NALT) k = 0;
             MW = alt_cand[k][0]; NW = alt_cand[k][1];

@@ -60,20 +60,6 @@ size_t gru_fused_lds(int C, int TH, int TW, int es) {
     return C == 16 ? (es == 2 ? gru_lds2<16, 2>(TH, TW) : gru_lds2<16, 4>(TH, TW)) : (es == 2 ? gru_lds2<20, 2>(TH, TW) : gru_lds2<20, 4>(TH, TW));
 }
 
-// N independent accumulators against one weight fragment; the split type's three terms go term by term so that no MFMA
-// waits for its predecessor
-template <int N> __device__ __forceinline__ void gru_mma(f32x4* acc, const Frag<f32s>& w, const Frag<f32s>* x) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.lo, x[i].hi, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x[i].lo, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.hi, x[i].hi, acc[i], 0, 0, 0);
-}
-template <int N, typename T> __device__ __forceinline__ void gru_mma(f32x4* acc, const Frag<T>& w, const Frag<T>* x) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) mma(acc[i], w, x[i]);
-}
 // acc[0..MT) += W(ks) * X(m-tile, ks) for the wave's K steps, pixel fragments read four m-tiles at a time
 template <typename T, int MT, int KSP, int KS, int NQ8, int PW, int CSL>
 __device__ __forceinline__ void gru_conv(f32x4* acc, const Frag<T>* w, const T* patch, const int* base, int ks0, int g) {
@@ -91,10 +77,10 @@ __device__ __forceinline__ void gru_conv(f32x4* acc, const Frag<T>* w, const T* 
                 Frag<T> xf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (m0 + i < MT) xf[i].load_lds(patch + base[m0 + i] + ko);
-                if (MT - m0 >= 4) gru_mma<4>(acc + m0, w[j], xf);
-                else if (MT - m0 == 3) gru_mma<3>(acc + m0, w[j], xf);
-                else if (MT - m0 == 2) gru_mma<2>(acc + m0, w[j], xf);
-                else gru_mma<1>(acc + m0, w[j], xf);
+                if (MT - m0 >= 4) mma_n<4>(acc + m0, w[j], xf);
+                else if (MT - m0 == 3) mma_n<3>(acc + m0, w[j], xf);
+                else if (MT - m0 == 2) mma_n<2>(acc + m0, w[j], xf);
+                else mma_n<1>(acc + m0, w[j], xf);
             }
         }
     }

@@ -232,6 +232,27 @@ def test_fused_inverted_residual_blocks_forced_tiles(gc, monkeypatch, tile):
     assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
 
 
+@pytest.mark.parametrize("variant", ["off"] + [str(v) for v in range(12)])
+def test_decoder_convs_with_weights_in_registers_forced(gc, monkeypatch, variant):
+    """conv_cat (the decoder's upsample + concat + conv + BN + ReLU layers with the weight fragments in registers, K split over
+    the waves) with each of its 12 variants (4 tiles x 3 wave layouts) forced where the layer admits it, and switched off
+    (conv_kxk): odd-sized maps, a batch index, all arithmetic modes, every tap."""
+    if variant == "off":
+        monkeypatch.setenv("RVM_CONV_REG", "0")
+    else:
+        monkeypatch.setenv("RVM_CONV_REG_VAR", variant)
+    monkeypatch.setenv("RVM_AUTOTUNE", "0")
+    w = gc.run("fp32", H=150, W=201, ds=0.8, T=2, B=2, verbose=False)
+    for k, v in w.items():
+        assert v < TOL32, (k, v, w)
+    w = gc.run("fp16", H=540, W=960, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < TOL16 and w["pha"] < TOL16, w
+    for k in ("x1", "x2", "x3", "hid"):
+        assert w[k] < 1e-4, w
+    w = gc.run("fp16fast", H=122, W=218, ds=0.5, T=2, verbose=False)
+    assert w["fgr"] < 1e-2 and w["pha"] < 1e-2, w
+
+
 @pytest.mark.parametrize("tile", ["off", "4,8", "8,8", "4,16", "8,16"])
 def test_fused_convgru_forced_tiles(gc, monkeypatch, tile):
     """gru_fused (decode1 / decode2: gate conv, r * h, candidate conv and the state blend as ONE launch per time step) with
