@@ -112,6 +112,13 @@ struct MbfArgs {
     unsigned invTWi, invCq;
     int mulE, mulP;
     int off_e, off_d, off_w, lds_total, red_bytes;
+    // features[1] folded in (stride-2 block with 16 input channels only): the block's input is computed in place from the
+    // stem output - depthwise 3x3 + ReLU, 16 x 16 project, residual - and also written out (the decoder's f1 skip)
+    const void* pre_x;                      // stem output [N][Hi*Wi][16], or null: x is read as it is
+    const float* pre_dw_w; const float* pre_dw_b;   // [9][16], [16]
+    const float* pre_pj_w; const float* pre_pj_b;   // [16 in][16 out], [16]
+    void* pre_y;                            // features[1] output [N][Hi*Wi][16]
+    int pre_pw, pre_npx; unsigned inv_pre_pw;       // stem patch: (THi + 2) x (TWi + 2) pixels (derived)
 };
 bool mbf_supported(int stride, int KSe, int act);    // a kernel instantiation exists for the combination
 bool mbf_prepare(MbfArgs& a, int es);                // fills the derived fields; false: the tile does not fit the kernel

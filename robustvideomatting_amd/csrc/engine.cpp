@@ -1125,6 +1125,15 @@ int build_plan(rvm_ctx* c) {
                 a.wp = wb + b.project.w; a.KSp = b.project.KS; a.NTp = b.project.NT; a.pbias = (const float*)(wb + b.project.bias);
                 a.res = b.res ? cur : nullptr; a.Cout = b.row.cout; a.C = exp;
                 a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = b.dw.stride;
+                // features[1] (depthwise 3x3 + 16 x 16 project + residual on the stem output) folded into features[2]: its
+                // launch, just planned, is dropped again; its output buffer stays (the f1 skip, written by the fused kernel)
+                const bool pre = i == 1 && c->mb[0].pj && c->mb[0].dw.act == ACT_RELU && stem_out && !c->launches.empty() &&
+                                 c->launches.back().name == "mb1.dw3_project" && !(getenv("RVM_MB1_FOLD") && atoi(getenv("RVM_MB1_FOLD")) == 0);
+                if (pre) {
+                    a.pre_x = stem_out; a.pre_y = cur;
+                    a.pre_dw_w = (const float*)(wb + c->mb[0].dw.w); a.pre_dw_b = (const float*)(wb + c->mb[0].dw.bias);
+                    a.pre_pj_w = (const float*)(wb + c->mb[0].pj_w); a.pre_pj_b = (const float*)(wb + c->mb[0].pj_b);
+                }
                 // Tile candidates (rows x columns of output pixels).  One frame: the launch is a chain of round trips, so
                 // the smallest per-block work that still keeps the grid within one round of CUs wins; many frames: plan-time
                 // measurement decides (larger tiles recompute less halo).
@@ -1145,6 +1154,7 @@ int build_plan(rvm_ctx* c) {
                     valid[nvalid++] = k;
                 }
                 if (nvalid > 0) {
+                    if (pre) c->launches.pop_back();
                     int pick = valid[tune_pick("mb" + std::to_string(i + 1) + ".fused", nvalid, model)];
                     if (const char* e = getenv("RVM_MBF_TILE")) {       // test hook: "rows,cols" forces that tile where it is valid
                         int th = 0, tw = 0;
@@ -1159,8 +1169,8 @@ int build_plan(rvm_ctx* c) {
                     if (getenv("RVM_VERBOSE") && c->arena)
                         fprintf(stderr, "[rvm] mb%d.fused tile %dx%d blocks %d lds %zu\n", i + 1, a.THo, a.TWo, a.tiles_x * a.tiles_y * B, (size_t)a.lds_total);
                     add("mb" + std::to_string(i + 1) + ".fused",
-                        2.0 * B * ((double)Hi * Wi * curC * exp + (double)npix * exp * 9 + (double)npix * exp * b.row.cout),
-                        ((double)B * (Hi * Wi * curC + npix * b.row.cout * (b.res ? 2 : 1)) + (double)curC * exp + 10.0 * exp + (double)exp * b.row.cout) * es,
+                        2.0 * B * ((double)Hi * Wi * curC * exp + (double)npix * exp * 9 + (double)npix * exp * b.row.cout + (pre ? (double)Hi * Wi * (16 * 9 + 256) : 0.0)),
+                        ((double)B * (Hi * Wi * curC * (pre ? 2 : 1) + npix * b.row.cout * (b.res ? 2 : 1)) + (double)curC * exp + 10.0 * exp + (double)exp * b.row.cout) * es,
                         [=](hipStream_t st, const FrameIO&) {
                             if constexpr (std::is_same<T, float>::value) { if (split) { launch_mbf<f32s>(a, B, st); return; } }
                             launch_mbf<T>(a, B, st);

@@ -27,6 +27,7 @@ constexpr int MBF_NPW = 2;           // expand n-tiles per wave, at most (NTe <=
 constexpr int MBF_XU = 4;            // staging loads per thread: one round covers the padded halo (host-checked)
 constexpr int MBF_MTP = 2;           // m-tiles (16 output pixels) of a tile, at most
 constexpr int MBF_NTP = 5;           // project n-tiles (Cout <= 80), at most
+constexpr int MBF_PREW = 144 + 16 + 256 + 16;   // floats of the folded features[1]: depthwise [9][16] + bias, project [16][16] + bias
 
 // Geometry and LDS map of a tile, derived once on the host: every instruction of address arithmetic in the kernel is paid
 // by all the waves that share a SIMD.
@@ -63,6 +64,13 @@ bool mbf_prepare(MbfArgs& a, int es) {
     if (total > 160 * 1024) return false;
     if (a.res && (a.stride != 1 || a.Cin != a.Cout)) return false;
     a.off_e = (int)off_e; a.off_d = (int)off_d; a.off_w = (int)off_w; a.lds_total = (int)total; a.red_bytes = (int)red;
+    if (a.pre_x) {
+        if (a.stride != 2 || a.KSe != 1 || a.Cin != 16 || a.act != ACT_RELU) return false;
+        a.pre_pw = a.TWi + 2; a.pre_npx = (a.THi + 2) * a.pre_pw;
+        a.inv_pre_pw = 0xFFFFFFFFu / (unsigned)a.pre_pw + 1u;
+        if (a.pre_npx * 4 > MBF_NTH * MBF_XU) return false;              // one staging round
+        if ((size_t)a.pre_npx * 64 + MBF_PREW * 4 > off_d - off_e) return false;    // the stem patch borrows the expanded halo's area
+    }
     return true;
 }
 
@@ -73,7 +81,7 @@ template <int ACT> __device__ __forceinline__ float mbf_act(float v) {
     else return v * __builtin_amdgcn_fmed3f(v + 3.f, 0.f, 6.f) * (1.f / 6.f);
 }
 
-template <typename T, int S, int KSE, int ACT, int NTP>
+template <typename T, int S, int KSE, int ACT, int NTP, bool PRE = false>
 __global__ __launch_bounds__(MBF_NTH) void mbconv_fused(MbfArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) char mbf_smem[];
@@ -92,13 +100,31 @@ __global__ __launch_bounds__(MBF_NTH) void mbconv_fused(MbfArgs a) {
     const T* xn = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.Cin;
     f32x4 xv[MBF_XU];
     bool xok[MBF_XU];
+    [[maybe_unused]] f32x4 prew = f32x4{0, 0, 0, 0};
+    if constexpr (PRE) {
+        // the stem patch one pixel around the halo (features[1]'s depthwise taps), and features[1]'s weights
+        const T* sn = (const T*)a.pre_x + (size_t)n * a.Hi * a.Wi * 16;
 #pragma unroll
-    for (int u = 0; u < MBF_XU; ++u) {
-        const int it = tid + u * MBF_NTH, row = it / QX, q = it - row * QX;
-        const int ry = (int)__umulhi((unsigned)row, a.invTWi), rx = row - ry * a.TWi;
-        const int iy = iy0 + ry, ix = ix0 + rx;
-        xok[u] = row < a.NPXi && q < cinq && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-        xv[u] = ld4f(xn + (xok[u] ? (iy * a.Wi + ix) * a.Cin + q * 4 : 0));
+        for (int u = 0; u < MBF_XU; ++u) {
+            const int it = tid + u * MBF_NTH, p = it >> 2, q = it & 3;
+            const int py = (int)__umulhi((unsigned)p, a.inv_pre_pw), px = p - py * a.pre_pw;
+            const int iy = iy0 - 1 + py, ix = ix0 - 1 + px;
+            xok[u] = p < a.pre_npx && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            xv[u] = ld4f(sn + (xok[u] ? (iy * a.Wi + ix) * 16 + q * 4 : 0));
+        }
+        if (tid < MBF_PREW / 4) {
+            const float* src = tid < 36 ? a.pre_dw_w + tid * 4 : (tid < 40 ? a.pre_dw_b + (tid - 36) * 4 : (tid < 104 ? a.pre_pj_w + (tid - 40) * 4 : a.pre_pj_b + (tid - 104) * 4));
+            prew = *(const f32x4*)src;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < MBF_XU; ++u) {
+            const int it = tid + u * MBF_NTH, row = it / QX, q = it - row * QX;
+            const int ry = (int)__umulhi((unsigned)row, a.invTWi), rx = row - ry * a.TWi;
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            xok[u] = row < a.NPXi && q < cinq && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            xv[u] = ld4f(xn + (xok[u] ? (iy * a.Wi + ix) * a.Cin + q * 4 : 0));
+        }
     }
     // expand weights.  NTe <= 8: wave = (n-tile, m-group), one n-tile; else wave w owns n-tiles w and w + 8, all m-tiles
     const bool two = a.NTe > MBF_NWV;
@@ -143,10 +169,25 @@ __global__ __launch_bounds__(MBF_NTH) void mbconv_fused(MbfArgs a) {
     // chains); the partial sums meet in LDS and wave nt < NTp finishes n-tile nt
     const bool actP = wave < a.KSp;
     // ---- halo to LDS; depthwise weights to LDS; zero the K padding of the depthwise output's fragments
+    if constexpr (PRE) {
+        f32x4* sbuf = (f32x4*)(mbf_smem + a.off_e);                   // [pre_npx][4 quads] stem patch, fp32; then the weights
 #pragma unroll
-    for (int u = 0; u < MBF_XU; ++u) {
-        const int it = tid + u * MBF_NTH, row = it / QX, q = it - row * QX;
-        if (it < nitems) stp4(xbuf + row * a.CSLx, q * 4, xok[u] ? xv[u] : f32x4{0, 0, 0, 0});
+        for (int u = 0; u < MBF_XU; ++u) {
+            const int it = tid + u * MBF_NTH;
+            if (it < a.pre_npx * 4) sbuf[it] = xok[u] ? xv[u] : f32x4{0, 0, 0, 0};     // zero outside the image: the depthwise conv's padding
+        }
+        if (tid < MBF_PREW / 4) sbuf[a.pre_npx * 4 + tid] = prew;
+        // K padding of the input fragments (channels 16..31) and the m-tile tail
+        for (int it = tid; it < nitems; it += MBF_NTH) {
+            const int row = it >> 3, q = it & 7;
+            if (q >= 4 || row >= a.NPXi) stp4(xbuf + row * a.CSLx, q * 4, f32x4{0, 0, 0, 0});
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < MBF_XU; ++u) {
+            const int it = tid + u * MBF_NTH, row = it / QX, q = it - row * QX;
+            if (it < nitems) stp4(xbuf + row * a.CSLx, q * 4, xok[u] ? xv[u] : f32x4{0, 0, 0, 0});
+        }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int i = tid + u * MBF_NTH; if (i < 10 * cq4) *(f32x4*)(wd + i * 4) = dwr[u]; }
@@ -155,6 +196,47 @@ __global__ __launch_bounds__(MBF_NTH) void mbconv_fused(MbfArgs a) {
         for (int i = tid; i < a.TP * a.padq; i += MBF_NTH) {
             const int p = a.padq > 1 ? (int)__umulhi((unsigned)i, invp) : i, q = i - p * a.padq;
             stp4(dbuf + p * a.CSLd, a.C + q * 4, f32x4{0, 0, 0, 0});
+        }
+    }
+    if constexpr (PRE) {
+        // ---- features[1] on the halo: item = (pixel, half of the 16 output channels); depthwise 3x3 + ReLU on all 16
+        //      channels, then the 16 x 16 project in fp32 + bias + the stem value (mobilenetv3.py: InvertedResidual without
+        //      expand, residual) -> the expand's input fragments, and to memory for the pixels this tile owns (all of the halo
+        //      but its first row and column, which the neighbouring tiles own)
+        __syncthreads();
+        const f32x4* sbuf = (const f32x4*)(mbf_smem + a.off_e);
+        const f32x4* pw4 = sbuf + a.pre_npx * 4;                       // [36] dw, [4] dw bias, [64] project, [4] bias
+        T* f1n = (T*)a.pre_y + (size_t)n * a.Hi * a.Wi * 16;
+        for (int it = tid; it < a.NPXi * 2; it += MBF_NTH) {
+            const int p = it >> 1, h = it & 1;
+            const int ry = (int)__umulhi((unsigned)p, a.invTWi), rx = p - ry * a.TWi;
+            const f32x4* s0 = sbuf + (ry * a.pre_pw + rx) * 4;         // top-left tap
+            float d[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 acc = pw4[36 + q];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc += s0[(ky * a.pre_pw + kx) * 4 + q] * pw4[(ky * 3 + kx) * 4 + q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d[q * 4 + r] = fmaxf(acc[r], 0.f);
+                    if constexpr (sizeof(T) == 2) d[q * 4 + r] = (float)(f16)d[q * 4 + r];      // as the depthwise output would be stored
+                }
+            }
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            const bool inb = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int qo = 2 * h + e;
+                f32x4 o = pw4[104 + qo];
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci) o += d[ci] * pw4[40 + ci * 4 + qo];
+                o += s0[(a.pre_pw + 1) * 4 + qo];                       // residual: the block's input
+                stp4(xbuf + p * a.CSLx, qo * 4, inb ? o : f32x4{0, 0, 0, 0});
+                if (inb && ry >= 1 && rx >= 1) st4f(f1n + (iy * a.Wi + ix) * 16 + qo * 4, o);
+            }
         }
     }
     __syncthreads();
@@ -314,6 +396,11 @@ template <typename T> static bool mbf_dispatch(const MbfArgs& a, const dim3& gri
         if (launch) hipLaunchKernelGGL((mbconv_fused<T, S_, K_, A_, P_>), grid, dim3(MBF_NTH), (size_t)a.lds_total, s, a); \
         else (void)hipFuncSetAttribute((const void*)mbconv_fused<T, S_, K_, A_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         return true; }
+    if (a.stride == 2 && a.KSe == 1 && a.act == ACT_RELU && (a.pre_x || !launch)) {
+        if (launch) hipLaunchKernelGGL((mbconv_fused<T, 2, 1, ACT_RELU, 2, true>), grid, dim3(MBF_NTH), (size_t)a.lds_total, s, a);
+        else (void)hipFuncSetAttribute((const void*)mbconv_fused<T, 2, 1, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (launch) return true;
+    }
     RVM_MBF_CASE(2, 1, ACT_RELU, 2) RVM_MBF_CASE(1, 1, ACT_RELU, 2) RVM_MBF_CASE(2, 2, ACT_HSWISH, 5) RVM_MBF_CASE(1, 3, ACT_HSWISH, 5)
 #undef RVM_MBF_CASE
     return false;
