@@ -949,7 +949,7 @@ int build_plan(rvm_ctx* c) {
                 const double cost = blk * (per_cu == 2 && nper > 1 ? 0.75 * nper : nper) * 0.62;     // (0.62: on the scale of the conv_kxk model above, which reads low)
                 if (cost < best - 1e-9) { best = cost; model = reg_first + r; }
             }
-            int pidx = tune_pick(name, reg_first + nreg, model, nreg > 0);       // with conv_cat in the list: always measured at plan time
+            int pidx = tune_pick(name, reg_first + nreg, model);
             if (const char* e = getenv("RVM_CONV_REG_VAR")) {        // test hook: force that conv_cat variant where it applies
                 for (int r = 0; r < nreg; ++r) if (reg_var[r] == atoi(e)) pidx = reg_first + r;
             }
@@ -978,7 +978,7 @@ int build_plan(rvm_ctx* c) {
             MW = cand[pick][0]; NW = cand[pick][1];
         } else if (Lp == alt && alt_ok) {
             // the chunked packing, one block per tile looping over the chunks
-            int k = tune_pick(name, alt_first + NALT + nreg, 0, nreg > 0) - alt_first;
+            int k = tune_pick(name, alt_first + NALT + nreg, 0) - alt_first;
             if (alt_force >= 0) k = alt_force;
             if (k < 0 || k >= NALT) k = 0;
             MW = alt_cand[k][0]; NW = alt_cand[k][1];
