@@ -331,7 +331,7 @@ class _NullWriter:
         pass
 
 
-def driver_pipeline(a, dev, wl_key="4k", T=24, chunk=4):
+def driver_pipeline(a, dev, wl_key="4k", T=64, chunk=4):
     """PCIe-inclusive rate of the driver loop (convert_video: host frames in, composed uint8 frames out) on an
     in-memory clip: the tensor-throughput `value` excludes host traffic like the reference's protocol does; this is what a
     caller with frames in host memory gets.  Two sources: uint8 frames (a decoder's output, 3 B / pixel up) and fp32 frames

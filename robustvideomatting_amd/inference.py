@@ -193,13 +193,13 @@ def convert_video(model,
         # the reference's constant, rounded like its tensor (inference.py:116)
         bgr = [float(v) for v in torch.tensor([120, 255, 155], dtype=dtype).div(255)]
     dev = torch.device(device)
-    pipe = _Pipeline(dev) if dev.type == "cuda" else None
+    pipe = _pipeline_for(dev) if dev.type == "cuda" else None
     u8src = bool(getattr(source, "yields_uint8", False))
     try:
         with torch.no_grad():
             rec = [None] * 4
             n = len(source)
-            pending = None                                   # the previous chunk's outputs, still on their way to the host
+            pending = []                                     # earlier chunks' outputs, still on their way to the host (oldest first)
             for k, start in enumerate(range(0, n, seq_chunk)):
                 stop = min(start + seq_chunk, n)
                 whole = source.chunk(start, stop) if hasattr(source, "chunk") else None
@@ -241,19 +241,18 @@ def convert_video(model,
                     if writer_com is not None:
                         mode = native.COMPOSE_GREEN if output_type == 'video' else native.COMPOSE_RGBA
                         outs.append((writer_com, compose_u8(fgr, pha, mode, bgr)))
-                # the frames start their way back now; the PREVIOUS chunk's frames (long arrived) go to the writers
+                # the frames start their way back now
                 if pipe is not None:
-                    ticket = pipe.download(k, outs)
-                    if pending is not None:
-                        pipe.deliver(pending)
-                    pending = ticket
+                    pending.append(pipe.download(k, outs))
+                    while len(pending) >= pipe.DEPTH:           # chunk k - DEPTH + 1 (long arrived) goes to the writers
+                        pipe.deliver(pending.pop(0))
                 else:
                     for w, fr in outs:
                         w.write(fr.cpu().numpy())
                 if progress:
                     print("\r%d / %d frames" % (min(start + seq_chunk, n), n), end="", flush=True)
-            if pending is not None:
-                pipe.deliver(pending)
+            for p in pending:
+                pipe.deliver(p)
             if progress:
                 print()
     finally:
@@ -263,23 +262,27 @@ def convert_video(model,
 
 
 class _Pipeline:
-    """Double-buffered host <-> device staging for convert_video: pinned buffers, an upload stream and a download stream
-    beside the compute stream (the reference pins and copies ``non_blocking``, inference.py:79,127).  Buffer set k % 2
-    serves chunk k; a set is reused only after the copies that touched it have completed (events)."""
+    """Host <-> device staging for convert_video: pinned buffers, an upload stream and a download stream beside the compute
+    stream (the reference pins and copies ``non_blocking``, inference.py:79,127).  DEPTH buffer sets: set k % DEPTH serves
+    chunk k and is reused only after the copies that touched it have completed (events); the frames of chunk k go to the
+    writers while chunks k + 1 and k + 2 are on their way, so uploads and downloads run back to back and the loop's period
+    is the slowest of upload, compute and download rather than their partial sums."""
+
+    DEPTH = 3
 
     def __init__(self, device):
         self.device = device
         self.up = torch.cuda.Stream(device)
         self.down = torch.cuda.Stream(device)
-        self.host_in = [None, None]
-        self.up_done = [None, None]
-        self.host_out = [{}, {}]
+        self.host_in = [None] * self.DEPTH
+        self.up_done = [None] * self.DEPTH
+        self.host_out = [{} for _ in range(self.DEPTH)]
         self.c255 = torch.full((), 255.0, device=device)
 
     def upload(self, k, frames, dtype, u8):
         """frames: list of [3,H,W] host tensors (staged through a pinned buffer), or ONE pinned [T,3,H,W] tensor (copied from
-        where it lies; the caller keeps it alive and unchanged until the next-but-one upload)."""
-        j = k & 1
+        where it lies; the caller keeps it alive and unchanged until the chunk has been delivered)."""
+        j = k % self.DEPTH
         cur = torch.cuda.current_stream(self.device)
         if torch.is_tensor(frames):
             with torch.cuda.stream(self.up):
@@ -308,7 +311,7 @@ class _Pipeline:
         return d
 
     def download(self, k, outs):
-        j = k & 1
+        j = k % self.DEPTH
         cur = torch.cuda.current_stream(self.device)
         done = cur.record_event()
         ticket = []
@@ -330,6 +333,23 @@ class _Pipeline:
         ev.synchronize()
         for w, host, T in ticket:
             w.write(host[:T].numpy())
+
+
+_PIPELINES = {}
+
+
+def _pipeline_for(device):
+    """One staging pipeline per device for the life of the process: page-locking its buffers costs ~10 ms per 100 MB, more
+    than a short clip's whole conversion (release_staging() drops them)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _PIPELINES:
+        _PIPELINES[key] = _Pipeline(device)
+    return _PIPELINES[key]
+
+
+def release_staging():
+    """Free the pinned staging buffers convert_video keeps between calls."""
+    _PIPELINES.clear()
 
 
 class Converter:
