@@ -5,7 +5,6 @@ reference inference.py:121-129), so a node scales by pinning stream i to GPU
 i mod N for life.  There is no collective on the data path; the only
 communication is the host-side reduction of per-rank timings.
 """
-import time
 
 
 def shard_streams(n_streams, world_size, rank):
@@ -46,12 +45,3 @@ def aggregate_throughput(frames_local, seconds_local, dist=None, device=None):
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return f.item() / t.item(), f.item(), t.item()
-
-
-class Stopwatch:
-    def __enter__(self):
-        self.t0 = time.perf_counter()
-        return self
-
-    def __exit__(self, *a):
-        self.seconds = time.perf_counter() - self.t0
