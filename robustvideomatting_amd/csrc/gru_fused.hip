@@ -19,21 +19,54 @@
 
 constexpr int GRU_NTH = 512;
 
-__device__ __forceinline__ f32x4 ldp4(const f16* row, int c) { return ld4f(row + c); }
-__device__ __forceinline__ f32x4 ldp4(const float* row, int c) { return ld4f(row + c); }
-__device__ __forceinline__ f32x4 ldp4(const f32s* row, int c) {        // inverse of stp4: hi + lo
-    const f16* g = (const f16*)(row + (c & ~7)) + (c & 7);
-    return __builtin_convertvector(*(const f16x4*)g, f32x4) + __builtin_convertvector(*(const f16x4*)(g + 8), f32x4);
-}
+// The [x | h] halo patch in LDS, PLANE-MAJOR: one plane of 16-byte slots per 8-channel group (and per half of it: the split
+// type's hi / lo f16 halves, the fp32 type's first / last four floats), a pixel = one slot of each plane.  The 16 lanes of a
+// ds_read_b128 lane group read 16 consecutive pixels of ONE plane, or 8 + 8 pixels of two planes whose distance is a multiple of
+// 16 slots - 16 different bank sets either way (pixel-major rows put the two 8-channel groups of such a lane group 32 bytes
+// apart: two-way conflicts on a quarter of the banks, and the fragment reads bounded both convs).  Row pitch P = region width
+// (mod 16), so that the flat m-tiles stay on consecutive slots (mod 16) across a row wrap.
+template <typename T> struct GruPatch;
+template <> struct GruPatch<f16> {
+    static constexpr int NH = 1;
+    static __device__ __forceinline__ void store4(char* p, int plane, int slot, int q, f32x4 v) {      // quad q of the pixel at `slot` (its group's plane 0)
+        *(f16x4*)(p + ((q >> 1) * plane + slot) * 16 + (q & 1) * 8) = __builtin_convertvector(v, f16x4);
+    }
+    static __device__ __forceinline__ f32x4 load4(const char* p, int plane, int slot, int q) {
+        return __builtin_convertvector(*(const f16x4*)(p + ((q >> 1) * plane + slot) * 16 + (q & 1) * 8), f32x4);
+    }
+    static __device__ __forceinline__ void frag(Frag<f16>& f, const char* p, int plane, int slot) { f.v = *(const f16x8*)(p + slot * 16); }
+};
+template <> struct GruPatch<f32s> {
+    static constexpr int NH = 2;
+    static __device__ __forceinline__ void store4(char* p, int plane, int slot, int q, f32x4 v) {
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        char* b = p + ((q >> 1) * 2 * plane + slot) * 16 + (q & 1) * 8;
+        *(f16x4*)b = hi;
+        *(f16x4*)(b + plane * 16) = lo;
+    }
+    static __device__ __forceinline__ f32x4 load4(const char* p, int plane, int slot, int q) {             // hi + lo
+        const char* b = p + ((q >> 1) * 2 * plane + slot) * 16 + (q & 1) * 8;
+        return __builtin_convertvector(*(const f16x4*)b, f32x4) + __builtin_convertvector(*(const f16x4*)(b + plane * 16), f32x4);
+    }
+    static __device__ __forceinline__ void frag(Frag<f32s>& f, const char* p, int plane, int slot) {
+        f.hi = *(const f16x8*)(p + slot * 16); f.lo = *(const f16x8*)(p + (slot + plane) * 16);
+    }
+};
+template <> struct GruPatch<float> {
+    static constexpr int NH = 2;
+    static __device__ __forceinline__ void store4(char* p, int plane, int slot, int q, f32x4 v) {
+        *(f32x4*)(p + (q * plane + slot) * 16) = v;                      // quad q = group q / 2, half q % 2
+    }
+    static __device__ __forceinline__ f32x4 load4(const char* p, int plane, int slot, int q) { return *(const f32x4*)(p + (q * plane + slot) * 16); }
+    static __device__ __forceinline__ void frag(Frag<float>& f, const char* p, int plane, int slot) {
+        f.lo = *(const f32x4*)(p + slot * 16); f.hi = *(const f32x4*)(p + (slot + plane) * 16);
+    }
+};
 // gate activations on the hardware's exp2 / rcp (1 ulp each): the libm forms cost ~30 instructions per value, and a tile has
 // 24 of them per lane
 __device__ __forceinline__ float gru_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 __device__ __forceinline__ float gru_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177792681f * v)); }
-
-// patch row pitch in elements: the smallest pitch >= 2C of 4 (mod 8) words, so that the 16 pixel rows a b128 fragment read
-// touches spread over all banks
-constexpr int gru_csl(int C, int es) { return (2 * C * es / 4 + (12 - (2 * C * es / 4) % 8) % 8) * 4 / es; }
-static_assert(gru_csl(16, 2) == 40 && gru_csl(20, 2) == 40 && gru_csl(16, 4) == 36 && gru_csl(20, 4) == 44, "pitch");
 
 template <int C, int TH, int TW, int ES> struct GruGeo {
     static constexpr int CP = 2 * C, NQ8 = CP / 8, QN = CP / 4, KS = (9 * CP + 31) / 32;
@@ -48,9 +81,11 @@ template <int C, int TH, int TW, int ES> struct GruGeo {
     static constexpr int NP1 = RH * RW, MT1 = (NP1 + 15) / 16, M1 = (MT1 + WP1 - 1) / WP1;
     static constexpr int MT2 = TH * TW / 16, M2 = (MT2 + WP2 - 1) / WP2;
     static constexpr int NITEMS = PH * PW * QN, XU = (NITEMS + GRU_NTH - 1) / GRU_NTH;
-    static constexpr int CSL = gru_csl(C, ES);
+    static constexpr int NH = ES == 2 ? 1 : 2;                 // planes per 8-channel group
+    static constexpr int P = RW + 16;                          // patch row pitch in pixels (= slots): RW (mod 16), >= PW
+    static constexpr int PLANE = NH == 2 ? PH * P + (24 - (PH * P) % 16) % 16 : PH * P + (16 - (PH * P) % 16) % 16;   // slots per plane: 8 / 0 (mod 16)
     static constexpr int RED = (NP1K * NTIH * MT1 > NP2K * NTHH * MT2 ? NP1K * NTIH * MT1 : NP2K * NTHH * MT2) * 1024;   // bytes of K-slice partials
-    static constexpr int OFF_Z = PH * PW * CSL * ES, OFF_RED = OFF_Z + NP1 * ZC * 4, LDS = OFF_RED + RED;
+    static constexpr int OFF_Z = NQ8 * NH * PLANE * 16, OFF_RED = OFF_Z + NP1 * ZC * 4, LDS = OFF_RED + RED;
 };
 bool gru_fused_supported(int C, int es) { return (C == 16 || C == 20) && (es == 2 || es == 4); }
 template <int C, int ES> static constexpr size_t gru_lds2(int TH, int TW) {
@@ -60,23 +95,23 @@ size_t gru_fused_lds(int C, int TH, int TW, int es) {
     return C == 16 ? (es == 2 ? gru_lds2<16, 2>(TH, TW) : gru_lds2<16, 4>(TH, TW)) : (es == 2 ? gru_lds2<20, 2>(TH, TW) : gru_lds2<20, 4>(TH, TW));
 }
 
-// acc[0..MT) += W(ks) * X(m-tile, ks) for the wave's K steps, pixel fragments read four m-tiles at a time
-template <typename T, int MT, int KSP, int KS, int NQ8, int PW, int CSL>
-__device__ __forceinline__ void gru_conv(f32x4* acc, const Frag<T>* w, const T* patch, const int* base, int ks0, int g) {
+// acc[0..MT) += W(ks) * X(m-tile, ks) for the wave's K steps, pixel fragments read four m-tiles at a time; base[i] = slot of
+// m-tile i's pixel (this lane's) at tap (0, 0)
+template <typename T, int MT, int KSP, int KS, int NQ8, int P, int PLANE>
+__device__ __forceinline__ void gru_conv(f32x4* acc, const Frag<T>* w, const char* patch, const int* base, int ks0, int g) {
 #pragma unroll
     for (int j = 0; j < KSP; ++j) {
         const int ks = ks0 + j;
         if (ks < KS) {                                                 // (uniform per wave)
-            // 8-channel group q8 = 4 ks + g sits on tap q8 / NQ8, channels (q8 % NQ8) * 8; K tail (tap 9): zero weights, any finite operand
+            // 8-channel group q8 = 4 ks + g sits on tap q8 / NQ8, group q8 % NQ8; K tail (tap 9): zero weights, any finite operand
             const int q8 = ks * 4 + g, t9 = q8 / NQ8, tap = min(t9, 8), c8 = q8 - t9 * NQ8;
             const int dy = tap / 3, dx = tap - dy * 3;
-            const int ko = (dy * PW + dx) * CSL + c8 * 8;
+            const int ko = c8 * GruPatch<T>::NH * PLANE + dy * P + dx;
 #pragma unroll
             for (int m0 = 0; m0 < MT; m0 += 4) {
-                constexpr int dummy = 0; (void)dummy;
                 Frag<T> xf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (m0 + i < MT) xf[i].load_lds(patch + base[m0 + i] + ko);
+                for (int i = 0; i < 4; ++i) if (m0 + i < MT) GruPatch<T>::frag(xf[i], patch, PLANE, base[m0 + i] + ko);
                 if (MT - m0 >= 4) mma_n<4>(acc + m0, w[j], xf);
                 else if (MT - m0 == 3) mma_n<3>(acc + m0, w[j], xf);
                 else if (MT - m0 == 2) mma_n<2>(acc + m0, w[j], xf);
@@ -91,11 +126,11 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
     [[maybe_unused]] Stamper stamp;
     typedef GruGeo<C, TH, TW, (int)sizeof(T)> G;
     typedef typename std::conditional<sizeof(T) == 2, f16, float>::type TS;      // element type of x / h / hout in memory
-    constexpr int CSL = G::CSL, KS = G::KS, PW = G::PW, RW = G::RW, NP1 = G::NP1, MT1 = G::MT1, MT2 = G::MT2;
+    constexpr int KS = G::KS, PW = G::PW, RW = G::RW, P = G::P, PLANE = G::PLANE, NP1 = G::NP1, MT1 = G::MT1, MT2 = G::MT2;
     extern __shared__ __attribute__((aligned(16))) char gru_smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
-    T* patch = (T*)gru_smem;                                       // [PH * PW][CSL]
+    char* patch = gru_smem;                                        // [8-channel group][half][PLANE slots of 16 bytes]
     float* zbuf = (float*)(gru_smem + G::OFF_Z);                   // [NP1][ZC]
     f32x4* red = (f32x4*)(gru_smem + G::OFF_RED);                  // [K slice][n-tile][m-tile][lane]
     const int y0 = ty * TH, x0 = tx * TW;
@@ -141,7 +176,8 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
 #pragma unroll
     for (int u = 0; u < G::XU; ++u) {
         const int it = tid + u * GRU_NTH, pp = it / G::QN, q = it - pp * G::QN;
-        if (it < G::NITEMS) stp4(patch + pp * CSL, q * 4, xin[u] ? xv[u] : f32x4{0, 0, 0, 0});
+        const int py = pp / PW, px = pp - py * PW;
+        if (it < G::NITEMS) GruPatch<T>::store4(patch, PLANE, py * P + px, q, xin[u] ? xv[u] : f32x4{0, 0, 0, 0});
     }
     __syncthreads();
     stamp(1);
@@ -153,9 +189,9 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
         for (int i = 0; i < MT1; ++i) {
             acc[i] = f32x4{0, 0, 0, 0};
             const int p1 = min(i * 16 + l15, NP1 - 1), ry = p1 / RW, rx = p1 - ry * RW;
-            base[i] = (ry * PW + rx) * CSL;
+            base[i] = ry * P + rx;
         }
-        gru_conv<T, MT1, G::KSP1, KS, G::NQ8, PW, CSL>(acc, wih, patch, base, kp1 * G::KSP1, g);
+        gru_conv<T, MT1, G::KSP1, KS, G::NQ8, P, PLANE>(acc, wih, patch, base, kp1 * G::KSP1, g);
         if (kp1 < G::NP1K) {
 #pragma unroll
             for (int i = 0; i < MT1; ++i) red[((kp1 * G::NTIH + nt1) * MT1 + i) * 64 + lane] = acc[i];
@@ -178,9 +214,8 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gru_sigmoid(v[r]);
                     if (is_r) {
-                        const int ry = p1 / RW, rx = p1 - ry * RW;
-                        T* row = patch + ((ry + 1) * PW + rx + 1) * CSL;
-                        stp4(row, C + cb, v * ldp4(row, C + cb));
+                        const int ry = p1 / RW, rx = p1 - ry * RW, slot = (ry + 1) * P + rx + 1, q = (C + cb) >> 2;
+                        GruPatch<T>::store4(patch, PLANE, slot, q, v * GruPatch<T>::load4(patch, PLANE, slot, q));
                     } else {
                         *(f32x4*)(zbuf + p1 * G::ZC + cb) = v;
                     }
@@ -198,9 +233,9 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
         for (int i = 0; i < MT2; ++i) {
             acc[i] = f32x4{0, 0, 0, 0};
             const int p2 = i * 16 + l15, r = p2 / TW, cx = p2 - r * TW;
-            base[i] = ((r + 1) * PW + cx + 1) * CSL;
+            base[i] = (r + 1) * P + cx + 1;
         }
-        gru_conv<T, MT2, G::KSP2, KS, G::NQ8, PW, CSL>(acc, whh, patch, base, kp2 * G::KSP2, g);
+        gru_conv<T, MT2, G::KSP2, KS, G::NQ8, P, PLANE>(acc, whh, patch, base, kp2 * G::KSP2, g);
         if (kp2 < G::NP2K) {
 #pragma unroll
             for (int i = 0; i < MT2; ++i) red[((kp2 * G::NTHH + nt2) * MT2 + i) * 64 + lane] = acc[i];
