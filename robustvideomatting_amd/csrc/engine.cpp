@@ -1388,7 +1388,7 @@ int build_plan(rvm_ctx* c) {
             // 4 x 8, 1.4x at 8 x 16) but one frame has too few large tiles for 256 CUs; many frames: large tiles, measured at
             // plan time where the plan is tuned.
             static const int cand[4][2] = {{4, 8}, {8, 8}, {4, 16}, {8, 16}};
-            int model = 0; double best = 1e30;
+            int model = 0, valid[4], nvalid = 0; double best = 1e30;
             for (int k = 0; k < 4; ++k) {
                 const int th = cand[k][0], tw = cand[k][1], blocks = cdiv(Hh, th) * cdiv(Ww, tw) * Bs;
                 if (gru_fused_lds(C, th, tw, (int)es) > 160 * 1024) continue;
@@ -1401,13 +1401,14 @@ int build_plan(rvm_ctx* c) {
                 else occ = gru_fused_occupancy<T>(C, th, tw);
                 occ = std::min(occ, 2);
                 const double cost = (double)cdiv(blocks, 256 * occ) * (occ * mf + 3000.0);
-                if (cost < best - 1e-9) { best = cost; model = k; }
+                if (cost < best - 1e-9) { best = cost; model = nvalid; }
+                valid[nvalid++] = k;
             }
-            int pick = tune_pick(name + ".fused", 4, model);
+            int pick = valid[tune_pick(name + ".fused", nvalid, model)];
             if (const char* e = getenv("RVM_GRU_TILE")) {                   // test hook: "rows,cols"
                 int th = 0, tw = 0;
                 if (sscanf(e, "%d,%d", &th, &tw) == 2)
-                    for (int k = 0; k < 4; ++k) if (cand[k][0] == th && cand[k][1] == tw) pick = k;
+                    for (int k = 0; k < nvalid; ++k) if (cand[valid[k]][0] == th && cand[valid[k]][1] == tw) pick = valid[k];
             }
             fusedTH = cand[pick][0]; fusedTW = cand[pick][1];
             if (getenv("RVM_VERBOSE") && c->arena)

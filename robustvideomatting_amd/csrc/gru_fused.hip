@@ -78,14 +78,34 @@ template <int C, int TH, int TW, int ES> struct GruGeo {
     static constexpr int WP2 = 8 / NTHH, KSP2 = (KS + WP2 - 1) / WP2, NP2K = (KS + KSP2 - 1) / KSP2;
     static constexpr int ZC = NTG * 16;                        // channels of the z tile
     static constexpr int PH = TH + 4, PW = TW + 4, RH = TH + 2, RW = TW + 2;
-    static constexpr int NP1 = RH * RW, MT1 = (NP1 + 15) / 16, M1 = (MT1 + WP1 - 1) / WP1;
+    // m-tiles of the region: TW = 8 walks it flat (10-pixel rows); TW = 16 gives each row's first 16 pixels a tile and packs
+    // the two leftover columns of eight rows into one (both orders touch 16 different slots (mod 16) per tile, see P)
+    static constexpr bool SPLIT = TW == 16;
+    static constexpr int NP1 = RH * RW, MT1 = SPLIT ? RH + (RH * 2 + 15) / 16 : (NP1 + 15) / 16, M1 = (MT1 + WP1 - 1) / WP1;
     static constexpr int MT2 = TH * TW / 16, M2 = (MT2 + WP2 - 1) / WP2;
     static constexpr int NITEMS = PH * PW * QN, XU = (NITEMS + GRU_NTH - 1) / GRU_NTH;
     static constexpr int NH = ES == 2 ? 1 : 2;                 // planes per 8-channel group
-    static constexpr int P = RW + 16;                          // patch row pitch in pixels (= slots): RW (mod 16), >= PW
+    // patch row pitch in slots, >= PW. Flat order: RW (mod 16), so a tile that wraps a row continues at the next slot
+    // (mod 16). Split order: 22, whose multiples (mod 16) 0 6 12 2 8 14 4 10 leave room for the column pair beside each
+    static constexpr int P = SPLIT ? 22 : RW + 16;
     static constexpr int PLANE = NH == 2 ? PH * P + (24 - (PH * P) % 16) % 16 : PH * P + (16 - (PH * P) % 16) % 16;   // slots per plane: 8 / 0 (mod 16)
     static constexpr int RED = (NP1K * NTIH * MT1 > NP2K * NTHH * MT2 ? NP1K * NTIH * MT1 : NP2K * NTHH * MT2) * 1024;   // bytes of K-slice partials
     static constexpr int OFF_Z = NQ8 * NH * PLANE * 16, OFF_RED = OFF_Z + NP1 * ZC * 4, LDS = OFF_RED + RED;
+    // region pixel of lane-index i of the m-tile order (false: past the region), and the order's index of a pixel (< NP1)
+    static __device__ __forceinline__ bool rpix(int i, int& ry, int& rx) {
+        if constexpr (SPLIT) {
+            const int j = i - RH * 16;
+            ry = j < 0 ? i >> 4 : j >> 1; rx = j < 0 ? i & 15 : 16 + (j & 1);
+            return ry < RH;
+        } else {
+            ry = i / RW; rx = i - ry * RW;
+            return i < NP1;
+        }
+    }
+    static __device__ __forceinline__ int ridx(int ry, int rx) {
+        if constexpr (SPLIT) return rx < 16 ? ry * 16 + rx : RH * 16 + ry * 2 + rx - 16;
+        else return ry * RW + rx;
+    }
 };
 bool gru_fused_supported(int C, int es) { return (C == 16 || C == 20) && (es == 2 || es == 4); }
 template <int C, int ES> static constexpr size_t gru_lds2(int TH, int TW) {
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
     [[maybe_unused]] Stamper stamp;
     typedef GruGeo<C, TH, TW, (int)sizeof(T)> G;
     typedef typename std::conditional<sizeof(T) == 2, f16, float>::type TS;      // element type of x / h / hout in memory
-    constexpr int KS = G::KS, PW = G::PW, RW = G::RW, P = G::P, PLANE = G::PLANE, NP1 = G::NP1, MT1 = G::MT1, MT2 = G::MT2;
+    constexpr int KS = G::KS, PW = G::PW, P = G::P, PLANE = G::PLANE, MT1 = G::MT1, MT2 = G::MT2;
     extern __shared__ __attribute__((aligned(16))) char gru_smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
@@ -181,15 +201,16 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
     }
     __syncthreads();
     stamp(1);
-    // ---- IH: gate conv on the (TH + 2) x (TW + 2) region, flat m-tiles, the wave's slice of K
+    // ---- IH: gate conv on the (TH + 2) x (TW + 2) region, the wave's slice of K
     {
         f32x4 acc[MT1];
         int base[MT1];
 #pragma unroll
         for (int i = 0; i < MT1; ++i) {
             acc[i] = f32x4{0, 0, 0, 0};
-            const int p1 = min(i * 16 + l15, NP1 - 1), ry = p1 / RW, rx = p1 - ry * RW;
-            base[i] = ry * P + rx;
+            int ry, rx;
+            const bool ok = G::rpix(i * 16 + l15, ry, rx);
+            base[i] = ok ? ry * P + rx : 0;
         }
         gru_conv<T, MT1, G::KSP1, KS, G::NQ8, P, PLANE>(acc, wih, patch, base, kp1 * G::KSP1, g);
         if (kp1 < G::NP1K) {
@@ -210,11 +231,12 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
                 f32x4 v = b1;
 #pragma unroll
                 for (int p = 0; p < G::NP1K; ++p) v += red[((p * G::NTIH + nt1) * MT1 + mt) * 64 + lane];
-                if (p1 < NP1 && cb < C) {
+                int ry, rx;
+                if (G::rpix(p1, ry, rx) && cb < C) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gru_sigmoid(v[r]);
                     if (is_r) {
-                        const int ry = p1 / RW, rx = p1 - ry * RW, slot = (ry + 1) * P + rx + 1, q = (C + cb) >> 2;
+                        const int slot = (ry + 1) * P + rx + 1, q = (C + cb) >> 2;
                         GruPatch<T>::store4(patch, PLANE, slot, q, v * GruPatch<T>::load4(patch, PLANE, slot, q));
                     } else {
                         *(f32x4*)(zbuf + p1 * G::ZC + cb) = v;
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(GRU_NTH) void gru_fused(GruArgs a) {
             for (int p = 0; p < G::NP2K; ++p) cv += red[((p * G::NTHH + nt2) * MT2 + mt) * 64 + lane];
             if (opix[i] >= 0) {
                 const int p2 = mt * 16 + l15, r = p2 / TW, cx = p2 - r * TW;
-                const f32x4 z = *(const f32x4*)(zbuf + ((r + 1) * RW + cx + 1) * G::ZC + cb2);
+                const f32x4 z = *(const f32x4*)(zbuf + G::ridx(r + 1, cx + 1) * G::ZC + cb2);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) cv[k] = (1.f - z[k]) * hprev[i][k] + z[k] * gru_tanh(cv[k]);
                 st4f((TS*)a.hout + opix[i], cv);
