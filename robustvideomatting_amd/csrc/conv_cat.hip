@@ -30,6 +30,10 @@ __global__ __launch_bounds__(CCAT_NT, ((KSP <= 5 && TH * TW < 256) ? 4 : 2)) voi
     Frag<T> wf[KSP];
 #pragma unroll
     for (int j = 0; j < KSP; ++j) wf[j].loadw((const T*)a.w + ((size_t)ntg * a.KS + min(ks0 + j, a.KS - 1)) * 512, lane);
+    // the epilogue's bias quad, requested with the weights (a load issued after the K loop is a round trip on the block's critical path)
+    const int ch = ((int)blockIdx.y * NTB + nt) * 16 + g * 4;
+    const bool chok = ((int)blockIdx.y * NTB + nt) < a.NT && ch < a.Cout;
+    const f32x4 bias = *(const f32x4*)(a.bias + min(ch, a.NT * 16 - 4));
     // ---- the halo patch (every source by its own waves, conv_assign_waves)
     {
         int coff = 0;
@@ -100,9 +104,6 @@ __global__ __launch_bounds__(CCAT_NT, ((KSP <= 5 && TH * TW < 256) ? 4 : 2)) voi
     }
     __syncthreads();
     // ---- add the slices in order, bias, ReLU, store: wave = (n-tile, m-tiles wave / NTB + i (8 / NTB))
-    const int ch = ((int)blockIdx.y * NTB + nt) * 16 + g * 4;
-    const bool chok = ((int)blockIdx.y * NTB + nt) < a.NT && ch < a.Cout;
-    const f32x4 bias = *(const f32x4*)(a.bias + min(ch, a.NT * 16 - 4));
     constexpr int WPN = 8 / NTB;
 #pragma unroll
     for (int i = 0; i < (MT + WPN - 1) / WPN; ++i) {

@@ -58,9 +58,21 @@ __device__ __forceinline__ void st8f(float* p, F8 v) { *(f32x4*)p = v.lo; *(f32x
 // split type: plain fp32 in global memory
 __device__ __forceinline__ f32x4 ld4f(const f32s* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ void st4f(f32s* p, f32x4 v) { *(f32x4*)p = v; }
+// hi = RN16(v), lo = RN16(v - hi).  v - hi is exact in fp32, so lo is ONE rounding of fma(hi, -1, v): v_fma_mix{lo,hi}_f16
+// takes the f16 half and the fp32 value as they are - 2 + 4 instructions per 4 values instead of 2 + 4 conversions back +
+// 4 subtractions + 2 packed conversions (the compiler does not form the mix instructions from the subtraction; bit-equal
+// over all 2^32 inputs, tools/microbench/split_check.hip).  Every split-mode operand goes through here.
+__device__ __forceinline__ unsigned split_lo2(unsigned hi2, float a, float b) {
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi2), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi2), "v"(b));
+    return l;
+}
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
     hi = __builtin_convertvector(v, f16x4);
-    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+    const u32x2_t h = __builtin_bit_cast(u32x2_t, hi);
+    lo = __builtin_bit_cast(f16x4, u32x2_t{split_lo2(h[0], v[0], v[1]), split_lo2(h[1], v[2], v[3])});
 }
 // LDS halo-patch stores: 4 channels c..c+3 (c % 4 == 0) of the pixel whose row starts at `row`.
 // f16 / float: channel-major row.  split: per 8-channel group [8 x hi f16][8 x lo f16] (32 B).

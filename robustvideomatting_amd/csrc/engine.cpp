@@ -750,7 +750,7 @@ int build_plan(rvm_ctx* c) {
             sprep.shadow[r] = hseq32[r] + per * (TT - 1);
             sprep.out[r] = hin32[r];
             sprep.n[r] = (int)per;
-            sprep.blocks += (int)((per + 1023) >> 10);
+            sprep.blocks += (int)((per + 4095) >> 12);
         }
         sprep.bf = io16 == IO_BF16;
     }

@@ -861,7 +861,7 @@ template <typename T, int TCH, int LPO>
 __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
     [[maybe_unused]] Stamper stamp;
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    __shared__ float part[1024];
+    __shared__ __attribute__((aligned(16))) float part[4096];                  // [row group][I] partial sums (<= 1024 threads x 4 values)
     const int n = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
     constexpr int OPW = 64 / LPO;                                    // outputs per wave
     const int wave = tid >> 6, lane = tid & 63, row = lane / LPO, sub = lane % LPO;
@@ -903,7 +903,33 @@ __global__ __launch_bounds__(1024) void gemv_act(GemvArgs a) {
         if (a.xbias) s = act_f(s + a.xbias[i], a.xact);
         return s;
     };
-    if (a.I >= NTH || a.nparts == 1) {
+    const int C4 = a.I >> 2, RG = C4 > 0 ? NTH / C4 : 0;
+    if (a.I < NTH && a.nparts > 16 && (a.part_stride & 3) == 0 && a.nparts <= 16 * RG) {
+        // many partial rows of a short vector (the squeeze-excite layers: <= 256 rows of 120 .. 240 values): thread =
+        // (4-value column c4, row group rg) takes rows rg, rg + RG, ... - at most 16 - as 16-byte loads, ALL in flight at
+        // once, so the reduction costs one round trip instead of one per 16 rows; the groups meet in LDS in group order.
+        const int c4 = tid % C4, rg = tid / C4;
+        if (rg < RG) {
+            const float* xp = a.xin + (size_t)n * a.nparts * a.part_stride + 4 * c4;
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int pj = rg + j * RG;
+                v[j] = *(const f32x4*)(xp + (size_t)min(pj, a.nparts - 1) * a.part_stride);
+                if (pj >= a.nparts) v[j] = f32x4{0, 0, 0, 0};
+            }
+            *(f32x4*)(part + rg * a.I + 4 * c4) = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])))
+                                               + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        }
+        __syncthreads();
+        if (tid < a.I) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int gq = 0; gq < RG; ++gq) s += part[gq * a.I + tid];
+            s *= a.xscale;
+            xs[tid] = a.xbias ? act_f(s + xb, a.xact) : s;
+        }
+    } else if (a.I >= NTH || a.nparts == 1) {
         for (int i = tid; i < a.I; i += NTH) xs[i] = fin(psum(i, 0, 1), i);
     } else {
         const int G = min(NTH / a.I, a.nparts);
@@ -1089,6 +1115,11 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+    // the epilogues' bias quads (all three index them (n-tile) * 16 + g * 4), requested here: a load issued after the K loop
+    // is a round trip on the block's critical path
+    f32x4 biasq[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) biasq[ni] = *(const f32x4*)(a.bias + min(nt0 + ni, a.NT - 1) * 16 + g * 4);
 
     int gs = chunk0 * KSfull, buf = 0;                       // global K step at the start of the stage
     const int chunk_end = splitk ? chunk0 + 1 : a.nchunks;
@@ -1226,7 +1257,7 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
             for (int ni = 0; ni < NW; ++ni) {
                 const int ch = (nt0 + ni) * 16 + g * 4;
                 if (!nv[ni] || ch >= a.Cout) continue;
-                f32x4 v = acc[mi][ni] + *(const f32x4*)(a.bias + ch);
+                f32x4 v = acc[mi][ni] + biasq[ni];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 st4f((T*)a.y + pix * a.ys + ch, v);
@@ -1239,8 +1270,8 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
                     const int t = nt0 + ni;
                     const int c = (t >> 1) * 16 + g * 4;
                     if (!nv[ni] || c >= a.hC) continue;
-                    f32x4 rv = acc[mi][ni] + *(const f32x4*)(a.bias + t * 16 + g * 4);
-                    f32x4 zv = acc[mi][ni + 1] + *(const f32x4*)(a.bias + (t + 1) * 16 + g * 4);
+                    f32x4 rv = acc[mi][ni] + biasq[ni];
+                    f32x4 zv = acc[mi][ni + 1] + biasq[ni + 1];
                     f32x4 h = f32x4{0, 0, 0, 0};
                     if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, sizeof(T) == 2 || a.state16);
 #pragma unroll
@@ -1255,7 +1286,7 @@ __global__ __launch_bounds__(CONV_NT, (MW >= 5 ? 2 : 4)) void conv_kxk(ConvArgs 
             for (int ni = 0; ni < NW; ++ni) {
                 const int c = (nt0 + ni) * 16 + g * 4;
                 if (!nv[ni] || c >= a.hC) continue;
-                f32x4 cv = acc[mi][ni] + *(const f32x4*)(a.bias + c);
+                f32x4 cv = acc[mi][ni] + biasq[ni];
                 f32x4 h = f32x4{0, 0, 0, 0};
                 if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, sizeof(T) == 2 || a.state16);
                 const f32x4 z = *(const f32x4*)(a.z + pix * a.hC + c);
@@ -1447,6 +1478,26 @@ __global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
     f32x4 acc[NW];
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) acc[ni] = f32x4{0, 0, 0, 0};
+    // Wave 0's epilogue operands (bias quads; previous state and z of the ConvGRU epilogues) are requested HERE, in front
+    // of the K loop: asked for after the reduction they were one more L2 round trip on the block's critical path
+    // (~1 us of a 6-8 us launch).  Clamped addresses, unconditional within the wave.
+    const bool s16 = sizeof(T) == 2 || a.state16;
+    const size_t pix = ((size_t)n * H + y) * W + min(px, W - 1);
+    f32x4 e_bias[NW], e_h[NW], e_z[NW];
+    if (wave == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            e_bias[ni] = *(const f32x4*)(a.bias + min(nt0 + ni, a.NT - 1) * 16 + g * 4);
+            e_h[ni] = f32x4{0, 0, 0, 0}; e_z[ni] = e_h[ni];
+            if (a.epi == EPI_GRU_IH) {
+                if (NW >= 2 && !(ni & 1) && a.hprev) e_h[ni] = ld4x(a.hprev, pix * a.hC + min(((nt0 + ni) >> 1) * 16 + g * 4, a.hC - 4), s16);
+            } else if (a.epi != EPI_RELU) {
+                const int c = min((nt0 + ni) * 16 + g * 4, a.hC - 4);
+                if (a.hprev) e_h[ni] = ld4x(a.hprev, pix * a.hC + c, s16);
+                e_z[ni] = *(const f32x4*)(a.z + pix * a.hC + c);
+            }
+        }
+    }
     const int nst = (a.KS - wave + WS - 1) / WS;                     // this wave's K steps: wave, wave + WS, ...
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_step(min(wave + WS * p, a.KS - 1), p);
@@ -1484,14 +1535,12 @@ __global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
 
     // ---- epilogue (wave 0): lane holds channels g*4..g*4+3 of pixel px for every n-tile; same arithmetic as conv_kxk
     if (px >= W) return;
-    const size_t pix = ((size_t)n * H + y) * W + px;
-    const bool s16 = sizeof(T) == 2 || a.state16;
     if (a.epi == EPI_RELU) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
             const int ch = (nt0 + ni) * 16 + g * 4;
             if (!nv[ni] || ch >= a.Cout) continue;
-            f32x4 v = acc[ni] + *(const f32x4*)(a.bias + ch);
+            f32x4 v = acc[ni] + e_bias[ni];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             st4f((T*)a.y + pix * a.ys + ch, v);
@@ -1503,10 +1552,9 @@ __global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
                 const int t = nt0 + ni;
                 const int c = (t >> 1) * 16 + g * 4;
                 if (!nv[ni] || c >= a.hC) continue;
-                f32x4 rv = acc[ni] + *(const f32x4*)(a.bias + t * 16 + g * 4);
-                f32x4 zv = acc[ni + 1] + *(const f32x4*)(a.bias + (t + 1) * 16 + g * 4);
-                f32x4 h = f32x4{0, 0, 0, 0};
-                if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, s16);
+                f32x4 rv = acc[ni] + e_bias[ni];
+                f32x4 zv = acc[ni + 1] + e_bias[ni + 1];
+                const f32x4 h = e_h[ni];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { rv[r] = sigmoid_f(rv[r]) * h[r]; zv[r] = sigmoid_f(zv[r]); }
                 st4f((T*)a.rh + pix * a.hC + c, rv);
@@ -1518,10 +1566,8 @@ __global__ __launch_bounds__(64 * WS) void conv_sk(ConvArgs a) {
         for (int ni = 0; ni < NW; ++ni) {
             const int c = (nt0 + ni) * 16 + g * 4;
             if (!nv[ni] || c >= a.hC) continue;
-            f32x4 cv = acc[ni] + *(const f32x4*)(a.bias + c);
-            f32x4 h = f32x4{0, 0, 0, 0};
-            if (a.hprev) h = ld4x(a.hprev, pix * a.hC + c, s16);
-            const f32x4 z = *(const f32x4*)(a.z + pix * a.hC + c);
+            f32x4 cv = acc[ni] + e_bias[ni];
+            const f32x4 h = e_h[ni], z = e_z[ni];
 #pragma unroll
             for (int r = 0; r < 4; ++r) cv[r] = (1.f - z[r]) * h[r] + z[r] * tanhf(cv[r]);
             st4x(a.hout, pix * a.hC + c, s16, cv);
@@ -1595,25 +1641,35 @@ __device__ __forceinline__ float quad_lane(float v, int k) {        // value of 
 // states - element by element the kept fp32 value where it rounds to what the caller passed, else the caller's value.
 template <typename T16>
 __device__ __forceinline__ void state_prep(const StatePrep& sp, int blk, int tid) {
+    // a block = 4096 elements of one level: four independent (caller, kept) load pairs per thread in flight
     int l = 0, b0 = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int nb = (sp.n[k] + 1023) >> 10;
+        const int nb = (sp.n[k] + 4095) >> 12;
         if (l == k && blk >= b0 + nb) { l = k + 1; b0 += nb; }
     }
     const int n = l == 0 ? sp.n[0] : (l == 1 ? sp.n[1] : (l == 2 ? sp.n[2] : sp.n[3]));
     const void* in = l == 0 ? sp.in[0] : (l == 1 ? sp.in[1] : (l == 2 ? sp.in[2] : sp.in[3]));
     const float* sh = l == 0 ? sp.shadow[0] : (l == 1 ? sp.shadow[1] : (l == 2 ? sp.shadow[2] : sp.shadow[3]));
     float* out = l == 0 ? sp.out[0] : (l == 1 ? sp.out[1] : (l == 2 ? sp.out[2] : sp.out[3]));
-    const int i = ((blk - b0) << 10) + tid * 4;
-    if (i >= n) return;
-    f32x4 v = f32x4{0, 0, 0, 0};
-    if (in) {
-        const f32x4 h = ld4f((const T16*)in + i), k = *(const f32x4*)(sh + i);
+    const int i0 = ((blk - b0) << 12) + tid * 4;
+    f32x4 h[4], k[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = ((float)(T16)k[r] == h[r]) ? k[r] : h[r];
+    for (int j = 0; j < 4; ++j) {
+        const int i = min(i0 + j * 1024, n - 4);                    // (levels hold multiples of 4 elements)
+        if (in) { h[j] = ld4f((const T16*)in + i); k[j] = *(const f32x4*)(sh + i); }
     }
-    *(f32x4*)(out + i) = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 1024;
+        if (i >= n) continue;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((float)(T16)k[j][r] == h[j][r]) ? k[j][r] : h[j][r];
+        }
+        *(f32x4*)(out + i) = v;
+    }
 }
 // two neighbouring elements of a source row, loaded as one (element-aligned) access
 template <typename TIO> struct TIO2 { float a, b; };
