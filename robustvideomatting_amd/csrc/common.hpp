@@ -220,7 +220,7 @@ struct DgfWeights {                          // device blob layout (floats)
     float seg_w[16];  float seg_b;
 };
 struct DgfLowArgs {
-    void* hid;                              // [h][w][16]: read (dgf_lowres) or written (dgf_lowres_mfma, which computes it)
+    void* hid;                              // [h][w][16]: read (dgf_lowres); dgf_lowres_mfma computes it and writes it here unless null
     const void* s0; const DgfWeights* wt; float* ab; int h, w, tiles_x, fast;
     const void* mlp;                        // deep refiner: 9 MFMA weight fragments (hi/lo fp16), see pack in engine.cpp
     // dgf_lowres_mfma: the OutputBlock's second conv runs inside it

@@ -180,7 +180,9 @@ struct MbBlock {
     size_t pj_w = 0, pj_b = 0; bool pj = false;     // block 1: project weights as plain fp32 [Cin][Cout] + bias (run inside mbconv_ed)
 };
 
-struct Tap { const void* p; int B, H, W, C, Cs; bool is_float; };
+// fill: the tap's buffer is not written by the frame's own launches (the kernel that produces the tensor keeps it on chip);
+// rvm_debug_tap runs this first to compute it from what the last forward left in the arena
+struct Tap { const void* p; int B, H, W, C, Cs; bool is_float; std::function<void(hipStream_t)> fill; };
 
 struct FrameIO {
     const void* src; const void* r_in[4]; void* fgr; void* pha; void* r_out[4]; int64_t seg;
@@ -1505,6 +1507,12 @@ int build_plan(rvm_ctx* c) {
             }, 0, conv1_in_dgf ? &conv1_fn : nullptr)) return 1;
     }
     c->taps["hid"] = Tap{hid, B, c->h, c->w, HC, HC, false};
+    if (conv1_in_dgf) {
+        // hid stays in the refiner kernel's LDS on a refining pass (B * h * w * 64 bytes of stores nobody reads); the debug
+        // tap recomputes it from hidA with the stand-alone conv that a segmentation pass launches
+        const std::function<void(hipStream_t, const FrameIO&)> conv1 = conv1_fn;
+        c->taps["hid"].fill = [=](hipStream_t st) { FrameIO none; memset(&none, 0, sizeof none); conv1(st, none); };
+    }
 
     // ---- projection + refiner + clamp (model.py:61-68)
     const DgfWeights* dw = (const DgfWeights*)(wb + c->dgf);
@@ -1512,7 +1520,7 @@ int build_plan(rvm_ctx* c) {
     c->taps["ab"] = Tap{ab, B, c->h, c->w, 8, 8, true};
     {
         DgfLowArgs lo; memset(&lo, 0, sizeof lo);
-        lo.hid = hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
+        lo.hid = conv1_in_dgf ? nullptr : hid; lo.s0 = s[0]; lo.wt = dw; lo.ab = ab; lo.h = c->h; lo.w = c->w; lo.tiles_x = cdiv(c->w, 16);
         lo.fast = c->refiner == RVM_REFINER_FAST_GUIDED_FILTER;
         if (conv1_in_dgf) {
             lo.mlp = wb + c->dgf_mlp;
@@ -1529,7 +1537,7 @@ int build_plan(rvm_ctx* c) {
             const double dflops = lowpx * 2.0 * (64 + 4 * 9 * 4 + 24 * 16 + 16 * 16 + 16 * 4);
             if (conv1_in_dgf) {
                 const std::function<void(hipStream_t, const FrameIO&)> conv1 = conv1_fn;
-                add("decode0.conv1_dgf_lowres", dflops + lowpx * 2.0 * 9 * HC * HC, lowpx * (HC * es + HC * es + 4 * es + 32) + 9.0 * HC * HC * es,
+                add("decode0.conv1_dgf_lowres", dflops + lowpx * 2.0 * 9 * HC * HC, lowpx * (HC * es + 4 * es + 32) + 9.0 * HC * HC * es,     // hidA in, s0 in, A|b out (hid stays in LDS)
                     [=](hipStream_t st, const FrameIO& io) { if (io.seg) conv1(st, io); else launch_dgf_low<T>(lo, B, st); });
             } else {
                 add("dgf_lowres", dflops, lowpx * (20 * es + 32),
@@ -2046,6 +2054,7 @@ int rvm_debug_tap(rvm_ctx* c, const char* name, float* out, int64_t cap, int64_t
     if (cap < n) return fail("rvm_debug_tap: output too small");
     DEVGUARD(c->device);
     HIPCHK(hipDeviceSynchronize());
+    if (t.fill) { t.fill(nullptr); HIPCHK(hipDeviceSynchronize()); }
     const size_t es = t.is_float ? 4 : c->esize();
     const size_t pixels = (size_t)t.B * t.H * t.W;
     std::vector<char> raw(pixels * t.Cs * es);

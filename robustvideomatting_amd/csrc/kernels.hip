@@ -2074,6 +2074,8 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) cwf[ks].loadw((const TC*)a.cw + (size_t)ks * 512, lane);
     const f32x4 cb = *(const f32x4*)(a.cbias + g * 4);
+    // (the MLP's biases too: asked for where they are used they were a round trip in front of the first layer)
+    const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g), b3 = *(const f32x4*)wt.b3;
     f32x4 xr[2]; bool inb[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -2131,6 +2133,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
         }
     }
     stamp(2);
+    if (a.hid)                                                                  // (null: nobody reads hid from memory, it stays in LDS)
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
@@ -2209,7 +2212,6 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
     }
     stamp(6);
     // ---- MLP on the MFMA, tile by tile
-    const f32x4 b1 = *(const f32x4*)(wt.b1 + 4 * g), b2 = *(const f32x4*)(wt.b2 + 4 * g);
     const f32x4 z4 = f32x4{0, 0, 0, 0};
     f32x4 A = z4;
     {
@@ -2254,7 +2256,7 @@ __global__ __launch_bounds__(256) void dgf_lowres_mfma(DgfLowArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) if (g == t) A = m[t];
     }
-    A += f32x4{wt.b3[0], wt.b3[1], wt.b3[2], wt.b3[3]};
+    A += b3;
     const int gy = y0 + ly;
     if (gy >= a.h || gx >= a.w) return;
     const f32x4 bq = my - A * mx;
