@@ -164,6 +164,8 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     model = model.to(dev, tdt)
     model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")
+    pipe = a.pipeline == "on" and a.mode != "graph"
+    model.pipeline_frames(pipe)
     # the ring of step inputs: n_ring distinct frames (batches / chunks) of one synthetic clip per stream
     n_ring = _ring_frames(wl["H"], wl["W"], batch, chunk, es, a.src_ring)
     ring = []
@@ -226,6 +228,19 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     dt2, _ = timed(n2, ring, sync_each=True, collective=False)
     res["fps_single_src"] = n2 * batch * chunk / dt1
     res["fps_sync_every_frame"] = n2 * batch * chunk / dt2
+    res["frame_pipeline"] = bool(pipe)
+    if a.mode != "graph":
+        # the other schedule, same loop: every launch of a frame on the one stream (pipeline off) / the encoder phase of
+        # frame n+1 beside the decoder phase of frame n (on).  The plan cache keeps both kinds, so switching back is free.
+        model.pipeline_frames(not pipe)
+        with torch.no_grad():
+            for i in range(max(5, warmup // 2)):
+                runner.step(ring[i % n_ring])
+        dt3, _ = timed(n2, ring, collective=False)
+        res["fps_pipeline_on" if not pipe else "fps_pipeline_off"] = n2 * batch * chunk / dt3
+        model.pipeline_frames(pipe)
+        with torch.no_grad():
+            runner.step(ring[0])
     if rank != 0:
         return res
     # ---- live per-kernel timing (hipEvents on the stream the kernels are launched on)
@@ -383,6 +398,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU (BASELINE configs[4]: --gpus 8 --batch 8)")
     ap.add_argument("--chunk", type=int, default=1,
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
+    ap.add_argument("--pipeline", default="off", choices=["on", "off"],
+                    help="frame pipeline: the encoder phase of frame n+1 on a second stream beside the decoder phase of frame n")
     ap.add_argument("--src-ring", type=int, default=0,
                     help="distinct step inputs cycled through (0: as many as exceed the 256 MiB Infinity Cache; 1: the same input every step)")
     ap.add_argument("--driver-pipeline", action="store_true", help="only the PCIe-inclusive convert_video rate of --workload")

@@ -163,6 +163,21 @@ int rvm_profile_frame(rvm_ctx* ctx, const void* src, const void* const r_in[4], 
  * for a replay to be valid; the graph is re-captured when they change). 0 = eager (default). */
 int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
 
+/* Frame pipeline (no counterpart in the reference, whose ATen launches all go to one stream; for callers that send frames
+ * without waiting for the previous one, e.g. reference inference.py:122-141 with a device-side writer).
+ * The encoder phase of a frame - downsample, backbone, LR-ASPP (model/model.py:52-58) - does not depend on the recurrent
+ * state, so with the pipeline on it runs on a stream of the context's own, BESIDE the decoder / refiner phase
+ * (model/model.py:59-67) of the frame before, which stays on the caller's stream.  Results are bit-identical; fgr / pha /
+ * r_out are ordered on the caller's stream as always.  What changes is the contract for `src`: the encoder reads it on
+ * the context's stream, so it must be complete when rvm_forward is called - or ordered behind the HIP event handed to
+ * rvm_frame_pipeline_src_event just before that call (one-shot; e.g. the event of the upload that fills src).  src must
+ * stay untouched until work enqueued after the call on `hip_stream` could touch it (stream order on `hip_stream` is
+ * enough: the decoder phase waits for the encoder phase).  The setting applies to plans made from then on: call
+ * rvm_plan / rvm_plan_seq again after changing it.  Costs one more set of the encoder's buffers in the arena
+ * (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  Ignored in graph mode. 0 = off (default). */
+int rvm_set_frame_pipeline(rvm_ctx* ctx, int enabled);
+int rvm_frame_pipeline_src_event(rvm_ctx* ctx, void* hip_event);
+
 const char* rvm_last_error(void);
 const char* rvm_version(void);
 

@@ -238,6 +238,34 @@ struct rvm_ctx {
     float* split_ws = nullptr;                          // conv_kxk split-K partial sums, shared by the launches that use it
     size_t split_need = 0;
 
+    // Frame pipeline (rvm_set_frame_pipeline): the encoder phase of a frame (everything up to LR-ASPP: it does not depend
+    // on the recurrent state) runs on the context's own stream, beside the decoder phase of the frame before on the
+    // caller's stream.  The tensors the encoder hands to the decoder (and the encoder's scratch) exist twice in the arena
+    // - [set 0][set 1][decoder region] - and the plan is built once per set: launches / taps are set 0's, *_b set 1's.
+    bool pipe_req = false;                              // what rvm_set_frame_pipeline asked for (plans built from now on)
+    bool pipe = false;                                  // the active plan is (being) built for the pipeline
+    bool enc_phase = false;                             // build_plan: allocations and launches so far belong to the encoder phase
+    size_t enc_shift = 0, enc_bytes = 0;                // build_plan: offset of the set being built; size of one set
+    int n_enc = 0;                                      // launches [0, n_enc) are the encoder phase
+    std::vector<Launch> launches_b;
+    std::map<std::string, Tap> taps_b;
+    float* split_ws_enc = nullptr;                      // the encoder phase's own split-K workspace (the phases overlap)
+    int frame_set = 0, last_set = 0;                    // set of the next frame / of the last one (debug taps)
+    hipStream_t enc_stream = nullptr;
+    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr};
+    bool ev_dec_valid[2] = {false, false};
+    hipEvent_t src_event = nullptr;                     // one-shot: what the next frame's src waits for (null: src is complete)
+    // counters for the alternative ways of ordering the two streams (RVM_PIPE_SYNC, see forward_impl): frame k's phases write k
+    uint32_t* sig_enc = nullptr; uint32_t* sig_dec = nullptr;
+    uint32_t pipe_seq = 0;                              // frames sent through the pipeline; frame k's phases write k
+    int pipe_sync = 0;                                  // 0: undecided, 1: stream memory operations, 2: events, 3: flag kernels
+    hipStream_t last_dec_stream = nullptr;
+    // the encoder phase behind its first launch touches neither src nor the states nor the outputs: one HIP graph per
+    // buffer set, captured at the set's first frame - a frame then costs the host a dozen launches instead of 46, which
+    // is what keeps the two streams fed (eager, the host was the bound: 309 us per HD frame for 235 us of encoder chain)
+    hipGraphExec_t enc_exec[2] = {nullptr, nullptr};
+    bool enc_graph_off = false;                         // capture failed once / RVM_PIPE_GRAPH=0: eager launches
+
     // graph mode
     bool graph_mode = false;
     hipStream_t cap_stream = nullptr;
@@ -251,6 +279,9 @@ struct rvm_ctx {
         char* arena; size_t arena_bytes, arena_used;
         std::vector<Launch> launches; std::map<std::string, Tap> taps; std::map<std::string, int> tuned; std::vector<Tunable> tunable;
         float* split_ws; size_t split_need; std::vector<GraphEntry> graphs;
+        bool pipe = false; size_t enc_bytes = 0; int n_enc = 0; std::vector<Launch> launches_b; std::map<std::string, Tap> taps_b;
+        float* split_ws_enc = nullptr;
+        hipGraphExec_t enc_exec[2] = {nullptr, nullptr};
     };
     std::vector<Parked> parked;                       // back = most recently used
     void swap_plan(Parked& p) {
@@ -260,10 +291,14 @@ struct rvm_ctx {
         std::swap(arena, p.arena); std::swap(arena_bytes, p.arena_bytes); std::swap(arena_used, p.arena_used);
         launches.swap(p.launches); taps.swap(p.taps); tuned.swap(p.tuned); tunable.swap(p.tunable);
         std::swap(split_ws, p.split_ws); std::swap(split_need, p.split_need); graphs.swap(p.graphs);
+        std::swap(pipe, p.pipe); std::swap(enc_bytes, p.enc_bytes); std::swap(n_enc, p.n_enc);
+        launches_b.swap(p.launches_b); taps_b.swap(p.taps_b); std::swap(split_ws_enc, p.split_ws_enc);
+        std::swap(enc_exec[0], p.enc_exec[0]); std::swap(enc_exec[1], p.enc_exec[1]);
     }
     void free_parked() {
         for (auto& p : parked) {
             for (auto& g : p.graphs) (void)hipGraphExecDestroy(g.exec);
+            for (auto& e : p.enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
             if (p.arena) (void)hipFree(p.arena);
         }
         parked.clear();
@@ -282,13 +317,14 @@ struct rvm_ctx {
     void* arena_alloc(size_t bytes) {
         size_t off = (arena_used + 255) & ~size_t(255);
         arena_used = off + bytes;
-        return arena + off;     // arena == nullptr during the sizing pass
+        return arena + off + (enc_phase ? enc_shift : 0);     // arena == nullptr during the sizing pass
     }
     void drop_graphs() {
-        if (graphs.empty()) return;
+        if (graphs.empty() && !enc_exec[0] && !enc_exec[1]) return;
         (void)hipDeviceSynchronize();              // an exec may still be in flight on the caller's stream
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
+        for (auto& e : enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
     }
 };
 
@@ -712,6 +748,8 @@ int build_plan(rvm_ctx* c) {
     c->tunable.clear();
     c->arena_used = 0;
     c->split_need = 0;
+    c->enc_phase = c->pipe;
+    c->n_enc = 0;
     auto tune_pick = [&](const std::string& name, int ncand, int model_choice, bool always = false) {
         const std::string key = tune_key(name);
         bool seen = false;
@@ -744,7 +782,7 @@ int build_plan(rvm_ctx* c) {
     float* hin32[4] = {nullptr, nullptr, nullptr, nullptr};
     float* hseq32[4] = {nullptr, nullptr, nullptr, nullptr};
     StatePrep sprep; memset(&sprep, 0, sizeof sprep);
-    if (io16) {
+    auto state_buffers = [&]() {
         for (int r = 0; r < 4; ++r) {
             const size_t per = (size_t)Bs * lh[r + 1] * lw[r + 1] * rch[r];
             hin32[r] = fbuf(per);
@@ -755,7 +793,8 @@ int build_plan(rvm_ctx* c) {
             sprep.blocks += (int)((per + 4095) >> 12);
         }
         sprep.bf = io16 == IO_BF16;
-    }
+    };
+    if (io16 && !c->pipe) state_buffers();                  // (frame pipeline: with the decoder phase, below)
 
     // ---- downsample + pyramid (model.py:52-55, decoder.py:35-39)
     T* s[4];
@@ -832,11 +871,12 @@ int build_plan(rvm_ctx* c) {
                 c->split_need = std::max(c->split_need, (size_t)a.nsplit * B * HW * L.NT * 16 * sizeof(float));
             }
         }
+        const bool in_enc = c->enc_phase;                   // (frame pipeline: the phases have a split-K workspace each)
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
             [=](hipStream_t st, const FrameIO&) {
                 PwArgs b = a;
-                if (a.part) b.part = c->split_ws;
+                if (a.part) b.part = in_enc ? c->split_ws_enc : c->split_ws;
                 launch_pw_m<T>(b, B, cfg, st, split);
             });
         if (a.part) c->launches.back().nk = 2;
@@ -1072,9 +1112,10 @@ int build_plan(rvm_ctx* c) {
             if (getenv("RVM_VERBOSE") && c->arena) fprintf(stderr, "[rvm] %-16s wres %d (resident %zu B, staged %zu B)\n", name.c_str(), a.wres, lw, ls);
         }
         const double KK = (double)L.KD * L.KD;
+        const bool in_enc = c->enc_phase;
         auto fn = [=](hipStream_t st, const FrameIO& io) {
             ConvArgs b = a; fill(b, io);
-            if (a.part) b.part = c->split_ws;
+            if (a.part) b.part = in_enc ? c->split_ws_enc : c->split_ws;
             launch_conv3_m<T>(b, B, MW, NW, geo, st, split);
         };
         if (keep) { *keep = fn; return 0; }
@@ -1371,6 +1412,29 @@ int build_plan(rvm_ctx* c) {
     pw("aspp1_1x1", c->aspp1, f4, c->enc_out, HW4, aspp, AC, nullptr, nullptr, 0, gate, nullptr);
     c->taps["aspp"] = Tap{aspp, B, lh[4], lw[4], AC, AC, false};
 
+    // ---- phase boundary of the frame pipeline: everything above is independent of the recurrent state.  One set of the
+    // encoder's buffers ends here; the decoder region follows the second set.  The state preparation, part of the first
+    // launch otherwise, becomes the decoder phase's first launch (it reads the states the frame before produced).
+    c->n_enc = (int)c->launches.size();
+    if (c->pipe) {
+        const size_t E = (c->arena_used + 255) & ~size_t(255);
+        if (c->enc_shift && E != c->enc_bytes) return fail("rvm_plan: the two buffer sets of the frame pipeline disagree in size");
+        c->enc_bytes = E;
+        c->arena_used = 2 * E;
+        c->enc_phase = false;
+        if (io16) {
+            state_buffers();
+            const StatePrep sp0 = sprep;
+            double sbytes = 0;
+            for (int r = 0; r < 4; ++r) sbytes += (double)sp0.n[r] * (2 + 4 + 4);
+            add("state_prep", 0.0, sbytes, [=](hipStream_t st, const FrameIO& io) {
+                StatePrep sp = sp0;
+                for (int r = 0; r < 4; ++r) sp.in[r] = io.r_in[r];
+                launch_state_prep(sp, io16, st);
+            });
+        }
+    }
+
     // ---- recurrent decoder (decoder.py:17-27)
     // GRU on the second half `xb` (channel stride xs) of a block's features; state level idx 3..0 -> r4..r1
     const size_t ses = es;                          // element size of a state inside the plan (16-bit API states never get here)
@@ -1563,6 +1627,7 @@ int build_plan(rvm_ctx* c) {
         }
     }
     c->split_ws = c->split_need ? (float*)c->arena_alloc(c->split_need) : nullptr;
+    c->split_ws_enc = (c->pipe && c->split_need) ? (float*)c->arena_alloc(c->split_need) : c->split_ws;
     return plan_bad ? 1 : 0;
 }
 
@@ -1650,7 +1715,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (B < 1 || T < 1 || H < 1 || W < 1) return fail("rvm_plan: bad shape");
     if ((int64_t)B * T > 65535) return fail("rvm_plan: B*T exceeds the grid limit (65535)");
     if (!(ds > 0.0 && ds <= 1.0)) return fail("rvm_plan: downsample_ratio must be in (0, 1]");
-    if (c->planned && c->B == B && c->T == T && c->H == H && c->W == W && c->ds == ds) return 0;      // the active plan
+    if (c->planned && c->B == B && c->T == T && c->H == H && c->W == W && c->ds == ds && c->pipe == c->pipe_req) return 0;      // the active plan
     // park the active plan, then look for the requested one among the parked
     if (c->planned) {
         rvm_ctx::Parked p{};
@@ -1661,7 +1726,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     }
     for (size_t i = 0; i < c->parked.size(); ++i) {
         rvm_ctx::Parked& p = c->parked[i];
-        if (p.B == B && p.T == T && p.H == H && p.W == W && p.ds == ds) {
+        if (p.B == B && p.T == T && p.H == H && p.W == W && p.ds == ds && p.pipe == c->pipe_req) {
             c->swap_plan(p);
             c->parked.erase(c->parked.begin() + (long)i);
             c->planned = true;
@@ -1673,10 +1738,13 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     while (c->parked.size() > keep) {                   // least recently used first
         HIPCHK(hipDeviceSynchronize());
         for (auto& g : c->parked.front().graphs) (void)hipGraphExecDestroy(g.exec);
+        for (auto& e : c->parked.front().enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
         if (c->parked.front().arena) HIPCHK(hipFree(c->parked.front().arena));
         c->parked.erase(c->parked.begin());
     }
     c->B = B; c->T = T; c->H = H; c->W = W; c->ds = ds;
+    c->pipe = c->pipe_req;
+    c->ev_dec_valid[0] = c->ev_dec_valid[1] = false;    // (a new arena: nothing in flight reads it)
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
     if (c->h < 1 || c->w < 1) return fail("rvm_plan: downsampled frame is empty");
@@ -1686,13 +1754,20 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     if (c->arena) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->arena)); c->arena = nullptr; }      // (a failed earlier plan)
     c->planned = false;
     c->tuned.clear();
+    // a plan of the other kind (frame pipeline on / off) for this very shape: the same launches in another arena layout -
+    // take over its tile choices instead of measuring again (and the two kinds then give the same bits)
+    bool inherited = false;
+    for (const auto& p : c->parked)
+        if (p.B == B && p.T == T && p.H == H && p.W == W && p.ds == ds) { c->tuned = p.tuned; inherited = true; }
     // sizing pass (arena == nullptr), then the real pass
+    c->enc_shift = 0;
     int rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
     if (rc) return rc;
     c->arena_bytes = c->arena_used + 256;
     HIPCHK(hipMalloc((void**)&c->arena, c->arena_bytes));
     HIPCHK(hipMemset(c->arena, 0, c->arena_bytes));
     HIPCHK(hipDeviceSynchronize());                           // the caller's (possibly non-blocking) stream must see the zeros
+    c->enc_shift = 0;
     rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
     if (rc) return rc;
     {
@@ -1702,8 +1777,22 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
         const bool tune = e ? atoi(e) != 0 && ((int64_t)B * T > 1 || atoi(e) == 1)
                             : ((int64_t)B * T > 1 || c->variant == RVM_VARIANT_RESNET50);
         const bool off = e && atoi(e) == 0;               // the reproducible mode: model choices only
-        if (!off && (rc = autotune(c, !tune))) return rc;
+        if (!off && !inherited && (rc = autotune(c, !tune))) return rc;
     }
+    c->launches_b.clear(); c->taps_b.clear();
+    if (c->pipe) {
+        // the second buffer set: the same plan (same tile choices) with the encoder region one set further on
+        c->enc_shift = c->enc_bytes;
+        rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
+        if (!rc && c->arena_used + 256 > c->arena_bytes) rc = fail("rvm_plan: second buffer set outgrew the arena");
+        c->launches_b.swap(c->launches); c->taps_b.swap(c->taps);
+        c->enc_shift = 0;
+        if (rc) return rc;
+        rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
+        if (rc) return rc;
+        if (c->launches_b.size() != c->launches.size()) return fail("rvm_plan: the two buffer sets of the frame pipeline disagree");
+    }
+    c->frame_set = 0; c->last_set = 0;
     c->planned = true;
     return 0;
 }
@@ -1759,6 +1848,13 @@ void rvm_destroy(rvm_ctx* c) {
     (void)hipDeviceSynchronize();          // graphs / arena may still be in flight on the caller's streams
     c->drop_graphs();
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->enc_stream) (void)hipStreamDestroy(c->enc_stream);
+    if (c->sig_enc) (void)hipFree(c->sig_enc);
+    if (c->sig_dec) (void)hipFree(c->sig_dec);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ev_enc[k]) (void)hipEventDestroy(c->ev_enc[k]);
+        if (c->ev_dec[k]) (void)hipEventDestroy(c->ev_dec[k]);
+    }
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->arena) (void)hipFree(c->arena);
     c->free_parked();
@@ -1848,6 +1944,24 @@ int rvm_set_graph_mode(rvm_ctx* c, int enabled) {
     return 0;
 }
 
+int rvm_set_frame_pipeline(rvm_ctx* c, int enabled) {
+    if (!c) return fail("rvm_set_frame_pipeline: null ctx");
+    DEVGUARD(c->device);
+    const bool on = enabled != 0;
+    if (on == c->pipe_req) return 0;
+    // the arena layout differs between the two kinds of plan (the plan cache tells them apart): frames in flight finish
+    // here, and the next rvm_plan / rvm_plan_seq builds - or finds - a plan of the kind asked for
+    HIPCHK(hipDeviceSynchronize());
+    c->pipe_req = on;
+    c->ev_dec_valid[0] = c->ev_dec_valid[1] = false;
+    return 0;
+}
+int rvm_frame_pipeline_src_event(rvm_ctx* c, void* hip_event) {
+    if (!c) return fail("rvm_frame_pipeline_src_event: null ctx");
+    c->src_event = (hipEvent_t)hip_event;
+    return 0;
+}
+
 static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void* const r_out[4], void* hip_stream);
 
 int rvm_forward(rvm_ctx* c, const void* src, const void* const r_in[4], void* fgr, void* pha,
@@ -1882,6 +1996,104 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
     }
     hipStream_t st = (hipStream_t)hip_stream;
     DEVGUARD(c->device);                                     // launches, capture stream and graphs belong to the context's device
+    hipEvent_t src_ev = c->src_event;
+    c->src_event = nullptr;                                  // one-shot
+    if (!c->graph_mode && c->pipe && !c->launches_b.empty()) {
+        // Frame pipeline: encoder phase on the context's stream - after the decoder phase that last read this buffer set
+        // (two frames back) and after src's event if one was given -, decoder phase on the caller's stream after it.
+        const int p = c->frame_set;
+        auto& L = p ? c->launches_b : c->launches;
+        static const int dbg_only = getenv("RVM_PIPE_ONLY") ? atoi(getenv("RVM_PIPE_ONLY")) : 0;   // timing experiments: 1 / 2 = encoder / decoder phase only, 3 = one stream
+        if (!c->enc_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->enc_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming | hipEventReleaseToDevice));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_dec[k], hipEventDisableTiming | hipEventReleaseToDevice));
+            }
+            // How the two streams order each other.  Default: events (hipEventRecord / hipStreamWaitEvent, device-scope
+            // release).  RVM_PIPE_SYNC=memop: stream memory operations on counters in signal memory (hipStreamWriteValue32 /
+            // hipStreamWaitValue32); =kernel: a one-thread kernel publishes the frame number, a one-wave kernel polls for
+            // it (sleeping, gives up after 2 s).  Measured per HD frame: events 310 us, memop 328 us, kernel 304 us (one
+            // stream: 350 us) - the kernel form assumes that the two streams sit on different hardware queues, which
+            // nothing guarantees, so the events stay the default.
+            c->pipe_sync = 2;
+            const char* e = getenv("RVM_PIPE_SYNC");
+            const std::string mode = e ? e : "event";
+            int can = 0;
+            if (mode == "memop" && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can &&
+                hipExtMallocWithFlags((void**)&c->sig_enc, 8, hipMallocSignalMemory) == hipSuccess &&
+                hipExtMallocWithFlags((void**)&c->sig_dec, 8, hipMallocSignalMemory) == hipSuccess) c->pipe_sync = 1;
+            else if (mode == "kernel" && hipMalloc((void**)&c->sig_enc, 8) == hipSuccess && hipMalloc((void**)&c->sig_dec, 8) == hipSuccess) c->pipe_sync = 3;
+            if (c->pipe_sync != 2) {
+                HIPCHK(hipMemset(c->sig_enc, 0, 8)); HIPCHK(hipMemset(c->sig_dec, 0, 8)); HIPCHK(hipDeviceSynchronize());
+            } else (void)hipGetLastError();
+            if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: streams ordered by %s\n", c->pipe_sync == 1 ? "stream memory operations" : (c->pipe_sync == 3 ? "flag kernels" : "events"));
+        }
+        const bool memops = c->pipe_sync == 1, kern = c->pipe_sync == 3;
+        if ((memops || kern) && c->pipe_seq >= 0x7FFFFF00u) {          // (the counters compare as unsigned >=: start over long before they wrap)
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemset(c->sig_enc, 0, 8)); HIPCHK(hipMemset(c->sig_dec, 0, 8));
+            HIPCHK(hipDeviceSynchronize());
+            c->pipe_seq = 0;
+        }
+        if (dbg_only == 3) {
+            for (auto& f : L) f.fn(st, io);
+            c->last_set = p; c->frame_set = p ^ 1;
+            return 0;
+        }
+        const uint32_t k = ++c->pipe_seq;
+        // the encoder phase overwrites the buffer set the decoder phase of frame k - 2 read
+        if (kern) { if (k > 2) launch_flag_wait(c->sig_dec, k - 2, c->enc_stream); }
+        else if (memops) { if (k > 2) HIPCHK(hipStreamWaitValue32(c->enc_stream, c->sig_dec, k - 2, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
+        else if (c->ev_dec_valid[p]) HIPCHK(hipStreamWaitEvent(c->enc_stream, c->ev_dec[p], 0));
+        if (src_ev) HIPCHK(hipStreamWaitEvent(c->enc_stream, src_ev, 0));
+        int i0 = 0;
+        while (i0 < c->n_enc && L[i0].edge == 1) L[i0++].fn(c->enc_stream, io);        // the launch(es) that read src
+        if (!c->enc_exec[p] && !c->enc_graph_off && i0 < c->n_enc) {
+            const char* e = getenv("RVM_PIPE_GRAPH");
+            if (!(e && atoi(e) == 1)) c->enc_graph_off = true;   // measured no faster than eager launches (the host is not the bound): opt-in
+            else {
+                if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+                for (int i = i0; i < c->n_enc; ++i) L[i].fn(c->cap_stream, io);
+                const hipError_t launch_err = hipGetLastError();
+                const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);     // always ended: a stream left capturing poisons later calls
+                hipError_t inst_err = hipErrorUnknown;
+                if (launch_err == hipSuccess && end_err == hipSuccess && graph) inst_err = hipGraphInstantiate(&c->enc_exec[p], graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+                if (inst_err != hipSuccess) { c->enc_exec[p] = nullptr; c->enc_graph_off = true; (void)hipGetLastError(); }
+            }
+        }
+        if (dbg_only == 2) {}
+        else if (c->enc_exec[p]) HIPCHK(hipGraphLaunch(c->enc_exec[p], c->enc_stream));
+        else for (int i = i0; i < c->n_enc; ++i) L[i].fn(c->enc_stream, io);
+        // the decoder phase follows on the caller's stream
+        if (kern) {
+            launch_flag_set(c->sig_enc, k, c->enc_stream);
+            launch_flag_wait(c->sig_enc, k, st);
+            if (k > 1 && st != c->last_dec_stream) launch_flag_wait(c->sig_dec, k - 1, st);
+        } else if (memops) {
+            HIPCHK(hipStreamWriteValue32(c->enc_stream, c->sig_enc, k, 0));
+            HIPCHK(hipStreamWaitValue32(st, c->sig_enc, k, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            if (k > 1 && st != c->last_dec_stream)           // (a caller that changes streams between frames)
+                HIPCHK(hipStreamWaitValue32(st, c->sig_dec, k - 1, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        } else {
+            HIPCHK(hipEventRecord(c->ev_enc[p], c->enc_stream));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_enc[p], 0));
+            if (c->ev_dec_valid[p ^ 1] && st != c->last_dec_stream) HIPCHK(hipStreamWaitEvent(st, c->ev_dec[p ^ 1], 0));
+        }
+        c->last_dec_stream = st;
+        for (size_t i = (size_t)c->n_enc; i < L.size(); ++i) if (dbg_only != 1 || i + 1 == L.size()) L[i].fn(st, io);
+        if (kern) launch_flag_set(c->sig_dec, k, st);
+        else if (memops) HIPCHK(hipStreamWriteValue32(st, c->sig_dec, k, 0));
+        else { HIPCHK(hipEventRecord(c->ev_dec[p], st)); c->ev_dec_valid[p] = true; }
+        c->last_set = p; c->frame_set = p ^ 1;
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (src_ev) HIPCHK(hipStreamWaitEvent(st, src_ev, 0));
+    c->last_set = 0;
     if (!c->graph_mode) {
         for (auto& f : c->launches) f.fn(st, io);
         HIPCHK(hipGetLastError());
@@ -2045,8 +2257,9 @@ int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
 
 int rvm_debug_tap(rvm_ctx* c, const char* name, float* out, int64_t cap, int64_t shape[4]) {
     if (!c || !c->planned || !name) return fail("rvm_debug_tap: no plan");
-    auto it = c->taps.find(name);
-    if (it == c->taps.end()) return fail(std::string("rvm_debug_tap: unknown tap ") + name);
+    auto& taps = (c->last_set && !c->taps_b.empty()) ? c->taps_b : c->taps;     // the buffer set of the last forward
+    auto it = taps.find(name);
+    if (it == taps.end()) return fail(std::string("rvm_debug_tap: unknown tap ") + name);
     const Tap& t = it->second;
     shape[0] = t.B; shape[1] = t.C; shape[2] = t.H; shape[3] = t.W;
     const int64_t n = (int64_t)t.B * t.C * t.H * t.W;

@@ -1884,6 +1884,29 @@ template <typename T> void launch_down(const DownArgs& a_, int N, int io, hipStr
     if (a.stem_y) hipLaunchKernelGGL((downsample<T, T, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((downsample<T, T, false>), grid, dim3(256), 0, s, a);
 }
+// the state preparation as a launch of its own (frame pipeline: it belongs to the decoder phase there)
+template <typename T16> __global__ __launch_bounds__(256) void state_prep_k(StatePrep sp) { state_prep<T16>(sp, blockIdx.x, threadIdx.x); }
+void launch_state_prep(const StatePrep& sp, int io, hipStream_t s) {
+    if (sp.blocks <= 0) return;
+    if (io == IO_BF16) hipLaunchKernelGGL((state_prep_k<bf16>), dim3(sp.blocks), dim3(256), 0, s, sp);
+    else hipLaunchKernelGGL((state_prep_k<f16>), dim3(sp.blocks), dim3(256), 0, s, sp);
+}
+// Frame pipeline: ordering between its two streams by a counter in device memory.  flag_set (one thread) publishes a frame
+// number behind a phase; flag_wait (one wave) holds its stream until the number is there.  It sleeps between polls and
+// gives up after ~2 s of wall clock, so no wave can wait for ever.
+__global__ __launch_bounds__(64) void flag_set(unsigned* flag, unsigned k) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void flag_wait(const unsigned* flag, unsigned k) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - k) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ull) break;                // 100 MHz counter
+    }
+}
+void launch_flag_set(unsigned* flag, unsigned k, hipStream_t s) { hipLaunchKernelGGL(flag_set, dim3(1), dim3(64), 0, s, flag, k); }
+void launch_flag_wait(const unsigned* flag, unsigned k, hipStream_t s) { hipLaunchKernelGGL(flag_wait, dim3(1), dim3(64), 0, s, flag, k); }
 template void launch_down<f16>(const DownArgs&, int, int, hipStream_t);
 template void launch_down<float>(const DownArgs&, int, int, hipStream_t);
 

@@ -90,6 +90,8 @@ class MattingNetwork(nn.Module):
         self._ctx_key = None        # (device index, dtype)
         self._dirty = True          # parameters changed since the last upload
         self._graph = False
+        self._pipe = False
+        self.src_ready = None                       # frame pipeline: a torch.cuda.Event the next src is ordered behind (one-shot)
         self.fp16_arithmetic = "fp32"   # half() module: "fp32" = fp16 tensors, fp32 math inside (meets 2e-3);
         #                                 "fp16" = fp16 storage + fp16 MFMA inside (fastest, fp16 accuracy)
         self.chunk_batching = True  # [B,T,...] input: one native call per chunk (rvm_plan_seq) instead of T calls
@@ -162,6 +164,32 @@ class MattingNetwork(nn.Module):
             self._ctx.set_graph_mode(self._graph)
         return self
 
+    def pipeline_frames(self, on: bool = True):
+        """Frame pipeline (default: off).  The encoder phase of a frame (downsample, backbone, LR-ASPP:
+        model/model.py:52-58) does not depend on the recurrent state; with the pipeline on it runs on a stream of the
+        native context's own, beside the decoder / refiner phase (model/model.py:59-67) of the frame before on the
+        current stream.  Same bits; fgr / pha / r1..r4 are ordered on the current stream as always.  For callers that
+        send frames without waiting for each result (reference inference.py:122-141).  The contract for `src` changes:
+        it is read on the context's stream, so it must be COMPLETE when forward is called (e.g. a frame uploaded and
+        synchronised earlier, or produced on another stream) - or set `model.src_ready = event` (a recorded
+        torch.cuda.Event, one-shot) before the call.  A src this wrapper has to copy first (non-contiguous) is ordered
+        automatically.  Ignored in graph mode."""
+        self._pipe = bool(on)
+        if self._ctx is not None:
+            self._ctx.set_frame_pipeline(self._pipe)
+        return self
+
+    def _order_src(self, ctx, dev, copied):
+        if not self._pipe:
+            return
+        ev, self.src_ready = self.src_ready, None
+        if copied:                                  # produced on the current stream a moment ago
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        self._src_ev_hold = ev                      # the native side takes the raw handle: keep the event alive through the call
+        if ev is not None:
+            ctx.src_event(ev.cuda_event)
+
     def _native(self, device, dtype):
         if dtype == torch.float32:
             code = native.DTYPE_F32
@@ -179,6 +207,7 @@ class MattingNetwork(nn.Module):
                 self._ctx.close()
             self._ctx = native.Context(self.variant, self.refiner_kind, code, key[0])
             self._ctx.set_graph_mode(self._graph)
+            self._ctx.set_frame_pipeline(self._pipe)
             self._ctx_key = key
             self._dirty = True
             self._ring = {}
@@ -289,7 +318,8 @@ class MattingNetwork(nn.Module):
         ring = self._static_ring(ctx, shapes, dev, dt) if self._graph else None
         for t in range(T):
             f = frames[t]
-            if not f.is_contiguous():
+            copied = not f.is_contiguous()
+            if copied:
                 f = f.contiguous()
             if ring is not None:
                 # static state buffers => stable pointers => the captured HIP graph can be replayed
@@ -298,6 +328,7 @@ class MattingNetwork(nn.Module):
                 new = [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
             o0, o1 = out0[t], (None if seg else out1[t])
             rin = [r.data_ptr() if r is not None else 0 for r in rec]
+            self._order_src(ctx, dev, copied)
             if seg:
                 ctx.forward(f.data_ptr(), rin, 0, o0.data_ptr(), [n.data_ptr() for n in new], True, stream)
             else:
@@ -314,8 +345,10 @@ class MattingNetwork(nn.Module):
         every stage outside the ConvGRUs runs on all B*T frames at once; the native side wants time-major frames."""
         dev, dt = src.device, src.dtype
         tb = src.transpose(0, 1)                    # [T,B,3,H,W]; already contiguous when B == 1
-        if not tb.is_contiguous():
+        copied = not tb.is_contiguous()
+        if copied:
             tb = tb.contiguous()
+        self._order_src(ctx, dev, copied)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rin = [r.data_ptr() if r is not None else 0 for r in rec]
         if self._graph:
@@ -341,11 +374,13 @@ class MattingNetwork(nn.Module):
         C = 4 if mode == native.COMPOSE_RGBA else 3
         stream = torch.cuda.current_stream(dev).cuda_stream
         tb = src.transpose(0, 1) if five else src.unsqueeze(0)         # [T,B,3,H,W]
-        if not tb.is_contiguous():
+        copied = not tb.is_contiguous()
+        if copied:
             tb = tb.contiguous()
         out = torch.empty((T, B, H, W, C), device=dev, dtype=torch.uint8)
         steps = [(0, T)] if (chunk or T == 1) else [(t, 1) for t in range(T)]
         for t0, _ in steps:
+            self._order_src(ctx, dev, copied)
             new = self._ring_next(self._static_ring(ctx, shapes, dev, dt), rec) if self._graph else \
                 [torch.empty(s, device=dev, dtype=dt, memory_format=torch.channels_last) for s in shapes]
             ctx.forward_u8(tb[t0].data_ptr(), [r.data_ptr() if r is not None else 0 for r in rec], out[t0].data_ptr(),

@@ -19,7 +19,7 @@ REFINERS = {"deep_guided_filter": 0, "fast_guided_filter": 1}
 SYMBOLS = [
     "rvm_create", "rvm_destroy", "rvm_param_count", "rvm_param_name", "rvm_param_shape",
     "rvm_set_param", "rvm_finalize", "rvm_plan", "rvm_plan_seq", "rvm_memory_bytes", "rvm_trim", "rvm_state_shape", "rvm_forward", "rvm_forward_u8",
-    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_kernels", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_last_error", "rvm_version",
+    "rvm_debug_tap", "rvm_debug_stamps", "rvm_compose_u8", "rvm_metrics", "rvm_metrics_workspace", "rvm_metrics_static", "rvm_metrics_static_capacity", "rvm_launch_count", "rvm_launch_kernels", "rvm_launch_info", "rvm_profile_frame", "rvm_set_graph_mode", "rvm_set_frame_pipeline", "rvm_frame_pipeline_src_event", "rvm_last_error", "rvm_version",
 ]
 
 _lib = None
@@ -96,6 +96,10 @@ def lib():
     L.rvm_profile_frame.restype = ci
     L.rvm_set_graph_mode.argtypes = [vp, ci]
     L.rvm_set_graph_mode.restype = ci
+    L.rvm_set_frame_pipeline.argtypes = [vp, ci]
+    L.rvm_set_frame_pipeline.restype = ci
+    L.rvm_frame_pipeline_src_event.argtypes = [vp, vp]
+    L.rvm_frame_pipeline_src_event.restype = ci
     L.rvm_last_error.argtypes = []
     L.rvm_last_error.restype = ctypes.c_char_p
     L.rvm_version.argtypes = []
@@ -192,7 +196,7 @@ class Context:
 
     def plan(self, B, H, W, ds, T=1):
         """T > 1: a chunk of T frames per stream in one call (rvm_plan_seq; tensors time-major)."""
-        key = (B, H, W, float(ds), T)
+        key = (B, H, W, float(ds), T, getattr(self, "_pipe", False))
         if key != self.plan_key:
             check(lib().rvm_plan_seq(self._h, B, T, H, W, float(ds)), "rvm_plan_seq")
             self.plan_key = key
@@ -255,6 +259,15 @@ class Context:
 
     def set_graph_mode(self, on):
         check(lib().rvm_set_graph_mode(self._h, 1 if on else 0), "rvm_set_graph_mode")
+
+    def set_frame_pipeline(self, on):
+        """Encoder phase of frame n+1 beside the decoder phase of frame n (include/rvm_mi355x.h); plans made from now on."""
+        check(lib().rvm_set_frame_pipeline(self._h, 1 if on else 0), "rvm_set_frame_pipeline")
+        self._pipe = bool(on)
+
+    def src_event(self, hip_event):
+        """One-shot: the next forward's src is ordered behind this HIP event (frame pipeline only)."""
+        check(lib().rvm_frame_pipeline_src_event(self._h, ctypes.c_void_p(hip_event)), "rvm_frame_pipeline_src_event")
 
     def debug_tap(self, name):
         import torch
