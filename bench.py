@@ -144,6 +144,9 @@ def spawn_ranks(a):
     return rc if rc else 0
 
 
+PIPE_KEYS = ("frame_pipeline", "fps_pipeline_off", "fps_pipeline_on", "fps_sync_every_frame_pipelined")
+
+
 def _ring_frames(H, W, batch, chunk, es, ring):
     """How many distinct step inputs the src ring holds: enough that their total exceeds the 256 MiB Infinity Cache, so a
     frame is not served from cache when its turn comes again (a real stream brings a new frame every step)."""
@@ -164,7 +167,7 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     model = model.to(dev, tdt)
     model.fp16_arithmetic = "fp16" if a.dtype == "fp16fast" else "fp32"
     model.enable_graph(a.mode == "graph")
-    pipe = a.pipeline == "on" and a.mode != "graph"
+    pipe = a.pipeline == "on"
     model.pipeline_frames(pipe)
     # the ring of step inputs: n_ring distinct frames (batches / chunks) of one synthetic clip per stream
     n_ring = _ring_frames(wl["H"], wl["W"], batch, chunk, es, a.src_ring)
@@ -224,23 +227,35 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
     # then sits in the Infinity Cache) and the reference's loop, which synchronises after every frame
     # (inference_speed_test.py:45-47)
     n2 = max(20, min(steps, 100))
-    dt1, _ = timed(n2, ring[:1], collective=False)
-    dt2, _ = timed(n2, ring, sync_each=True, collective=False)
-    res["fps_single_src"] = n2 * batch * chunk / dt1
-    res["fps_sync_every_frame"] = n2 * batch * chunk / dt2
-    res["frame_pipeline"] = bool(pipe)
-    if a.mode != "graph":
-        # the other schedule, same loop: every launch of a frame on the one stream (pipeline off) / the encoder phase of
-        # frame n+1 beside the decoder phase of frame n (on).  The plan cache keeps both kinds, so switching back is free.
-        model.pipeline_frames(not pipe)
+
+    def schedule(on):
+        """Switch between the one-stream schedule and the frame pipeline (the plan cache keeps both kinds of plan)."""
+        model.pipeline_frames(on)
         with torch.no_grad():
-            for i in range(max(5, warmup // 2)):
+            for i in range(max(6, warmup // 2)):
                 runner.step(ring[i % n_ring])
+        torch.cuda.synchronize(dev)
+
+    dt1, _ = timed(n2, ring[:1], collective=False)
+    res["fps_single_src"] = n2 * batch * chunk / dt1
+    res["frame_pipeline"] = bool(pipe)
+    if pipe:
+        dt2p, _ = timed(n2, ring, sync_each=True, collective=False)
+        res["fps_sync_every_frame_pipelined"] = n2 * batch * chunk / dt2p
+    # the one-stream schedule (every launch of a frame on the caller's stream), same loop; the reference's protocol - a device
+    # synchronisation after every frame - is quoted on it: a caller that waits for each frame gains nothing from the pipeline
+    schedule(False)
+    if pipe:
         dt3, _ = timed(n2, ring, collective=False)
-        res["fps_pipeline_on" if not pipe else "fps_pipeline_off"] = n2 * batch * chunk / dt3
-        model.pipeline_frames(pipe)
-        with torch.no_grad():
-            runner.step(ring[0])
+        res["fps_pipeline_off"] = n2 * batch * chunk / dt3
+    dt2, _ = timed(n2, ring, sync_each=True, collective=False)
+    res["fps_sync_every_frame"] = n2 * batch * chunk / dt2
+    if not pipe:
+        schedule(True)
+        dt3, _ = timed(n2, ring, collective=False)
+        res["fps_pipeline_on"] = n2 * batch * chunk / dt3
+        schedule(False)
+    # (the per-launch profile below runs on the one-stream plan: its launches are the frame's, in order, on one stream)
     if rank != 0:
         return res
     # ---- live per-kernel timing (hipEvents on the stream the kernels are launched on)
@@ -398,7 +413,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU (BASELINE configs[4]: --gpus 8 --batch 8)")
     ap.add_argument("--chunk", type=int, default=1,
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
-    ap.add_argument("--pipeline", default="off", choices=["on", "off"],
+    ap.add_argument("--pipeline", default="on", choices=["on", "off"],
                     help="frame pipeline: the encoder phase of frame n+1 on a second stream beside the decoder phase of frame n")
     ap.add_argument("--src-ring", type=int, default=0,
                     help="distinct step inputs cycled through (0: as many as exceed the 256 MiB Infinity Cache; 1: the same input every step)")
@@ -447,7 +462,7 @@ def main():
             for key, wlk, b in (("4k", "4k", 1), ("hd_batch8", "hd", 8), ("hd_resnet50", "hd_resnet50", 1)):
                 r = measure(a, wlk, b, 1, 100, 10, dev, 0, 1, None)
                 also[key] = {k: r[k] for k in ("fps", "ms_per_step", "steps", "workload", "streams_per_gpu", "src_ring", "fps_single_src",
-                                               "fps_sync_every_frame", "roofline", "frame_roofline", "memory_bytes")}
+                                               "fps_sync_every_frame", "roofline", "frame_roofline", "memory_bytes") + PIPE_KEYS if k in r}
             also["driver_pipeline_4k"] = driver_pipeline(a, dev)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(WORKLOADS[a.workload])
@@ -464,6 +479,7 @@ def main():
                       "bf16": "bf16 tensors (MFMA on split hi/lo f16 operands, f32 accumulate)"}[a.dtype],
             "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": a.batch, "frames_per_step": a.batch * a.chunk, "chunk": a.chunk, "mode": a.mode,
+                       "frame_pipeline": a.pipeline == "on",
                        "src_ring": head["src_ring"],
                        "parallelism": "stream-sharded, %d independent stream(s), no collective" % (world * a.batch)},
             "roofline": head["roofline"], "cpu_baseline": cpu,
@@ -471,6 +487,9 @@ def main():
             # the same workload under the other two protocols (this rank): one input re-used every step (rounds 1-2; src then
             # stays in the 256 MiB Infinity Cache) and the reference's loop with a device synchronisation after every frame
             "fps_single_src": head["fps_single_src"], "fps_sync_every_frame": head["fps_sync_every_frame"],
+            # frame pipeline (encoder stages of the next frames on the context's own streams beside the decoder phase of
+            # this one): `value` is measured with it when --pipeline on (default); fps_pipeline_off / _on is the other schedule
+            **{k: head[k] for k in PIPE_KEYS if k in head},
             "memory_bytes": head.get("memory_bytes"),
         }
         if "fps_per_rank" in head:

@@ -174,7 +174,8 @@ int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
  * stay untouched until work enqueued after the call on `hip_stream` could touch it (stream order on `hip_stream` is
  * enough: the decoder phase waits for the encoder phase).  The setting applies to plans made from then on: call
  * rvm_plan / rvm_plan_seq again after changing it.  Costs one more set of the encoder's buffers in the arena
- * (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  Ignored in graph mode. 0 = off (default). */
+ * (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  In graph mode (rvm_set_graph_mode) the decoder phase
+ * replays as a HIP graph as well, one per (state pointers, buffer set). 0 = off (default). */
 int rvm_set_frame_pipeline(rvm_ctx* ctx, int enabled);
 int rvm_frame_pipeline_src_event(rvm_ctx* ctx, void* hip_event);
 

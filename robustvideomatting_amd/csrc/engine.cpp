@@ -238,33 +238,36 @@ struct rvm_ctx {
     float* split_ws = nullptr;                          // conv_kxk split-K partial sums, shared by the launches that use it
     size_t split_need = 0;
 
-    // Frame pipeline (rvm_set_frame_pipeline): the encoder phase of a frame (everything up to LR-ASPP: it does not depend
-    // on the recurrent state) runs on the context's own stream, beside the decoder phase of the frame before on the
-    // caller's stream.  The tensors the encoder hands to the decoder (and the encoder's scratch) exist twice in the arena
-    // - [set 0][set 1][decoder region] - and the plan is built once per set: launches / taps are set 0's, *_b set 1's.
+    // Frame pipeline (rvm_set_frame_pipeline).  The encoder phase of a frame (everything up to LR-ASPP) does not depend on
+    // the recurrent state: it is cut into `enc_stages` stages of consecutive launches, each on a stream of the context's
+    // own, and the decoder phase stays on the caller's stream - so stage j works on frame n + (enc_stages - j) while the
+    // decoder works on frame n.  enc_stages + 1 frames are in flight, so the tensors the encoder stages hand on (and
+    // their scratch) exist that many times in the arena - [set 0][set 1]...[decoder region] - and the plan is built once
+    // per set: launches / taps are set 0's, launch_sets / tap_sets the others'.
     bool pipe_req = false;                              // what rvm_set_frame_pipeline asked for (plans built from now on)
     bool pipe = false;                                  // the active plan is (being) built for the pipeline
+    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 2; 1..3)
+    int stage_end[4] = {0, 0, 0, 0};                    // encoder stage j = launches [stage_end[j - 1], stage_end[j])
     bool enc_phase = false;                             // build_plan: allocations and launches so far belong to the encoder phase
     size_t enc_shift = 0, enc_bytes = 0;                // build_plan: offset of the set being built; size of one set
     int n_enc = 0;                                      // launches [0, n_enc) are the encoder phase
-    std::vector<Launch> launches_b;
-    std::map<std::string, Tap> taps_b;
+    std::vector<std::vector<Launch>> launch_sets;
+    std::vector<std::map<std::string, Tap>> tap_sets;
     float* split_ws_enc = nullptr;                      // the encoder phase's own split-K workspace (the phases overlap)
     int frame_set = 0, last_set = 0;                    // set of the next frame / of the last one (debug taps)
-    hipStream_t enc_stream = nullptr;
-    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr};
-    bool ev_dec_valid[2] = {false, false};
+    hipStream_t enc_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_stage[4][4] = {};                     // [stage: encoder stages, then the decoder phase][set]
+    bool ev_dec_valid[4] = {false, false, false, false};
     hipEvent_t src_event = nullptr;                     // one-shot: what the next frame's src waits for (null: src is complete)
-    // counters for the alternative ways of ordering the two streams (RVM_PIPE_SYNC, see forward_impl): frame k's phases write k
-    uint32_t* sig_enc = nullptr; uint32_t* sig_dec = nullptr;
-    uint32_t pipe_seq = 0;                              // frames sent through the pipeline; frame k's phases write k
-    int pipe_sync = 0;                                  // 0: undecided, 1: stream memory operations, 2: events, 3: flag kernels
+    unsigned* sig_stage[4] = {nullptr, nullptr, nullptr, nullptr};   // RVM_PIPE_SYNC=kernel: frame counters per stage
+    uint32_t pipe_seq = 0;                              // frames sent through the pipeline; frame k's stages publish k
+    int pipe_sync = 0;                                  // 0: undecided, 2: events, 3: flag kernels
     hipStream_t last_dec_stream = nullptr;
-    // the encoder phase behind its first launch touches neither src nor the states nor the outputs: one HIP graph per
-    // buffer set, captured at the set's first frame - a frame then costs the host a dozen launches instead of 46, which
-    // is what keeps the two streams fed (eager, the host was the bound: 309 us per HD frame for 235 us of encoder chain)
-    hipGraphExec_t enc_exec[2] = {nullptr, nullptr};
-    bool enc_graph_off = false;                         // capture failed once / RVM_PIPE_GRAPH=0: eager launches
+    // An encoder stage behind the launch that reads src touches neither src nor the states nor the outputs: one HIP graph
+    // per (buffer set, stage), captured at the set's first frame.  With two encoder stages the host is the bound (46
+    // launches, ~280 us of enqueueing per HD frame for ~210 us of device time); a frame then costs it ~16 launches.
+    hipGraphExec_t stage_exec[4][3] = {};               // [set][stage]
+    bool stage_graph_off = false;                       // capture failed once / RVM_PIPE_GRAPH=0: eager launches
 
     // graph mode
     bool graph_mode = false;
@@ -279,9 +282,10 @@ struct rvm_ctx {
         char* arena; size_t arena_bytes, arena_used;
         std::vector<Launch> launches; std::map<std::string, Tap> taps; std::map<std::string, int> tuned; std::vector<Tunable> tunable;
         float* split_ws; size_t split_need; std::vector<GraphEntry> graphs;
-        bool pipe = false; size_t enc_bytes = 0; int n_enc = 0; std::vector<Launch> launches_b; std::map<std::string, Tap> taps_b;
+        bool pipe = false; size_t enc_bytes = 0; int n_enc = 0, enc_stages = 1, stage_end[4] = {0, 0, 0, 0};
+        std::vector<std::vector<Launch>> launch_sets; std::vector<std::map<std::string, Tap>> tap_sets;
         float* split_ws_enc = nullptr;
-        hipGraphExec_t enc_exec[2] = {nullptr, nullptr};
+        hipGraphExec_t stage_exec[4][3] = {};
     };
     std::vector<Parked> parked;                       // back = most recently used
     void swap_plan(Parked& p) {
@@ -292,13 +296,15 @@ struct rvm_ctx {
         launches.swap(p.launches); taps.swap(p.taps); tuned.swap(p.tuned); tunable.swap(p.tunable);
         std::swap(split_ws, p.split_ws); std::swap(split_need, p.split_need); graphs.swap(p.graphs);
         std::swap(pipe, p.pipe); std::swap(enc_bytes, p.enc_bytes); std::swap(n_enc, p.n_enc);
-        launches_b.swap(p.launches_b); taps_b.swap(p.taps_b); std::swap(split_ws_enc, p.split_ws_enc);
-        std::swap(enc_exec[0], p.enc_exec[0]); std::swap(enc_exec[1], p.enc_exec[1]);
+        launch_sets.swap(p.launch_sets); tap_sets.swap(p.tap_sets); std::swap(split_ws_enc, p.split_ws_enc);
+        std::swap(enc_stages, p.enc_stages);
+        for (int j = 0; j < 4; ++j) std::swap(stage_end[j], p.stage_end[j]);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 3; ++b) std::swap(stage_exec[a][b], p.stage_exec[a][b]);
     }
     void free_parked() {
         for (auto& p : parked) {
             for (auto& g : p.graphs) (void)hipGraphExecDestroy(g.exec);
-            for (auto& e : p.enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+            for (auto& row : p.stage_exec) for (auto& e : row) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
             if (p.arena) (void)hipFree(p.arena);
         }
         parked.clear();
@@ -320,11 +326,13 @@ struct rvm_ctx {
         return arena + off + (enc_phase ? enc_shift : 0);     // arena == nullptr during the sizing pass
     }
     void drop_graphs() {
-        if (graphs.empty() && !enc_exec[0] && !enc_exec[1]) return;
+        bool any = !graphs.empty();
+        for (auto& row : stage_exec) for (auto& e : row) any |= e != nullptr;
+        if (!any) return;
         (void)hipDeviceSynchronize();              // an exec may still be in flight on the caller's stream
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
-        for (auto& e : enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+        for (auto& row : stage_exec) for (auto& e : row) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
     }
 };
 
@@ -1420,7 +1428,7 @@ int build_plan(rvm_ctx* c) {
         const size_t E = (c->arena_used + 255) & ~size_t(255);
         if (c->enc_shift && E != c->enc_bytes) return fail("rvm_plan: the two buffer sets of the frame pipeline disagree in size");
         c->enc_bytes = E;
-        c->arena_used = 2 * E;
+        c->arena_used = (size_t)(c->enc_stages + 1) * E;
         c->enc_phase = false;
         if (io16) {
             state_buffers();
@@ -1738,13 +1746,18 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     while (c->parked.size() > keep) {                   // least recently used first
         HIPCHK(hipDeviceSynchronize());
         for (auto& g : c->parked.front().graphs) (void)hipGraphExecDestroy(g.exec);
-        for (auto& e : c->parked.front().enc_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+        for (auto& row : c->parked.front().stage_exec) for (auto& e : row) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
         if (c->parked.front().arena) HIPCHK(hipFree(c->parked.front().arena));
         c->parked.erase(c->parked.begin());
     }
     c->B = B; c->T = T; c->H = H; c->W = W; c->ds = ds;
     c->pipe = c->pipe_req;
-    c->ev_dec_valid[0] = c->ev_dec_valid[1] = false;    // (a new arena: nothing in flight reads it)
+    for (bool& v : c->ev_dec_valid) v = false;          // (a new arena: nothing in flight reads it)
+    c->enc_stages = 1;
+    if (c->pipe) {
+        const char* e = getenv("RVM_PIPE_STAGES");      // encoder stages (streams of the context's own): 1..3
+        c->enc_stages = e ? std::min(3, std::max(1, atoi(e))) : 2;
+    }
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
     if (c->h < 1 || c->w < 1) return fail("rvm_plan: downsampled frame is empty");
@@ -1779,18 +1792,24 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
         const bool off = e && atoi(e) == 0;               // the reproducible mode: model choices only
         if (!off && !inherited && (rc = autotune(c, !tune))) return rc;
     }
-    c->launches_b.clear(); c->taps_b.clear();
+    c->launch_sets.clear(); c->tap_sets.clear();
     if (c->pipe) {
-        // the second buffer set: the same plan (same tile choices) with the encoder region one set further on
-        c->enc_shift = c->enc_bytes;
-        rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
-        if (!rc && c->arena_used + 256 > c->arena_bytes) rc = fail("rvm_plan: second buffer set outgrew the arena");
-        c->launches_b.swap(c->launches); c->taps_b.swap(c->taps);
+        // the other buffer sets: the same plan (same tile choices) with the encoder region one set further on each time
+        for (int k = 1; k <= c->enc_stages; ++k) {
+            c->enc_shift = (size_t)k * c->enc_bytes;
+            rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
+            if (!rc && c->arena_used + 256 > c->arena_bytes) rc = fail("rvm_plan: a buffer set of the frame pipeline outgrew the arena");
+            c->launch_sets.push_back(std::move(c->launches)); c->tap_sets.push_back(std::move(c->taps));
+            c->launches.clear(); c->taps.clear();
+            if (rc) { c->enc_shift = 0; return rc; }
+        }
         c->enc_shift = 0;
-        if (rc) return rc;
         rc = c->dtype == RVM_DTYPE_F16 ? build_plan<f16>(c) : build_plan<float>(c);
         if (rc) return rc;
-        if (c->launches_b.size() != c->launches.size()) return fail("rvm_plan: the two buffer sets of the frame pipeline disagree");
+        for (const auto& L : c->launch_sets)
+            if (L.size() != c->launches.size()) return fail("rvm_plan: the buffer sets of the frame pipeline disagree");
+        // stages of equal launch counts (the encoder's launches are all of the same order: 5-10 us)
+        for (int j = 0; j < c->enc_stages; ++j) c->stage_end[j] = (int)((long)c->n_enc * (j + 1) / c->enc_stages);
     }
     c->frame_set = 0; c->last_set = 0;
     c->planned = true;
@@ -1848,13 +1867,9 @@ void rvm_destroy(rvm_ctx* c) {
     (void)hipDeviceSynchronize();          // graphs / arena may still be in flight on the caller's streams
     c->drop_graphs();
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-    if (c->enc_stream) (void)hipStreamDestroy(c->enc_stream);
-    if (c->sig_enc) (void)hipFree(c->sig_enc);
-    if (c->sig_dec) (void)hipFree(c->sig_dec);
-    for (int k = 0; k < 2; ++k) {
-        if (c->ev_enc[k]) (void)hipEventDestroy(c->ev_enc[k]);
-        if (c->ev_dec[k]) (void)hipEventDestroy(c->ev_dec[k]);
-    }
+    for (auto& e : c->enc_streams) if (e) (void)hipStreamDestroy(e);
+    for (auto& g : c->sig_stage) if (g) (void)hipFree(g);
+    for (auto& row : c->ev_stage) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->arena) (void)hipFree(c->arena);
     c->free_parked();
@@ -1953,7 +1968,7 @@ int rvm_set_frame_pipeline(rvm_ctx* c, int enabled) {
     // here, and the next rvm_plan / rvm_plan_seq builds - or finds - a plan of the kind asked for
     HIPCHK(hipDeviceSynchronize());
     c->pipe_req = on;
-    c->ev_dec_valid[0] = c->ev_dec_valid[1] = false;
+    for (bool& v : c->ev_dec_valid) v = false;
     return 0;
 }
 int rvm_frame_pipeline_src_event(rvm_ctx* c, void* hip_event) {
@@ -1998,97 +2013,120 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
     DEVGUARD(c->device);                                     // launches, capture stream and graphs belong to the context's device
     hipEvent_t src_ev = c->src_event;
     c->src_event = nullptr;                                  // one-shot
-    if (!c->graph_mode && c->pipe && !c->launches_b.empty()) {
-        // Frame pipeline: encoder phase on the context's stream - after the decoder phase that last read this buffer set
-        // (two frames back) and after src's event if one was given -, decoder phase on the caller's stream after it.
-        const int p = c->frame_set;
-        auto& L = p ? c->launches_b : c->launches;
-        static const int dbg_only = getenv("RVM_PIPE_ONLY") ? atoi(getenv("RVM_PIPE_ONLY")) : 0;   // timing experiments: 1 / 2 = encoder / decoder phase only, 3 = one stream
-        if (!c->enc_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&c->enc_stream, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
-                HIPCHK(hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming | hipEventReleaseToDevice));
-                HIPCHK(hipEventCreateWithFlags(&c->ev_dec[k], hipEventDisableTiming | hipEventReleaseToDevice));
-            }
-            // How the two streams order each other.  Default: events (hipEventRecord / hipStreamWaitEvent, device-scope
-            // release).  RVM_PIPE_SYNC=memop: stream memory operations on counters in signal memory (hipStreamWriteValue32 /
-            // hipStreamWaitValue32); =kernel: a one-thread kernel publishes the frame number, a one-wave kernel polls for
-            // it (sleeping, gives up after 2 s).  Measured per HD frame: events 310 us, memop 328 us, kernel 304 us (one
-            // stream: 350 us) - the kernel form assumes that the two streams sit on different hardware queues, which
-            // nothing guarantees, so the events stay the default.
+    if (c->pipe && !c->launch_sets.empty()) {
+        // Frame pipeline: encoder stage 0 waits for the decoder phase that last read this buffer set (sets = stages in
+        // flight) and for src's event if one was given; every later stage waits for the one before it on this frame; the
+        // decoder phase, on the caller's stream, for the last encoder stage.
+        const int NE = c->enc_stages, S = NE + 1, p = c->frame_set;
+        auto& L = p ? c->launch_sets[p - 1] : c->launches;
+        if (!c->enc_streams[0]) {
+            for (int j = 0; j < 3; ++j) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));
+            // device-scope release is all the ordering needs (the default, release to system, also writes the L2 back)
+            for (auto& row : c->ev_stage) for (auto& e : row) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
+            // How the streams order each other.  Default: events.  RVM_PIPE_SYNC=kernel: a one-thread kernel publishes the
+            // frame number behind a stage, a one-wave kernel polls for it in front of the next (sleeping between polls;
+            // gives up after 2 s) - measured 304 against 310 us per HD frame with one encoder stage, but it assumes that the
+            // streams sit on different hardware queues, which nothing guarantees; stream memory operations
+            // (hipStreamWaitValue32) measured slower than either (328 us).
             c->pipe_sync = 2;
             const char* e = getenv("RVM_PIPE_SYNC");
-            const std::string mode = e ? e : "event";
-            int can = 0;
-            if (mode == "memop" && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can &&
-                hipExtMallocWithFlags((void**)&c->sig_enc, 8, hipMallocSignalMemory) == hipSuccess &&
-                hipExtMallocWithFlags((void**)&c->sig_dec, 8, hipMallocSignalMemory) == hipSuccess) c->pipe_sync = 1;
-            else if (mode == "kernel" && hipMalloc((void**)&c->sig_enc, 8) == hipSuccess && hipMalloc((void**)&c->sig_dec, 8) == hipSuccess) c->pipe_sync = 3;
-            if (c->pipe_sync != 2) {
-                HIPCHK(hipMemset(c->sig_enc, 0, 8)); HIPCHK(hipMemset(c->sig_dec, 0, 8)); HIPCHK(hipDeviceSynchronize());
-            } else (void)hipGetLastError();
-            if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: streams ordered by %s\n", c->pipe_sync == 1 ? "stream memory operations" : (c->pipe_sync == 3 ? "flag kernels" : "events"));
+            if (e && std::string(e) == "kernel") {
+                for (auto& g : c->sig_stage) { HIPCHK(hipMalloc((void**)&g, 8)); HIPCHK(hipMemset(g, 0, 8)); }
+                HIPCHK(hipDeviceSynchronize());
+                c->pipe_sync = 3;
+            }
         }
-        const bool memops = c->pipe_sync == 1, kern = c->pipe_sync == 3;
-        if ((memops || kern) && c->pipe_seq >= 0x7FFFFF00u) {          // (the counters compare as unsigned >=: start over long before they wrap)
+        const bool kern = c->pipe_sync == 3;
+        if (kern && c->pipe_seq >= 0x7FFFFF00u) {            // (the counters compare as signed differences: start over long before they wrap)
             HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemset(c->sig_enc, 0, 8)); HIPCHK(hipMemset(c->sig_dec, 0, 8));
+            for (auto& g : c->sig_stage) HIPCHK(hipMemset(g, 0, 8));
             HIPCHK(hipDeviceSynchronize());
             c->pipe_seq = 0;
         }
-        if (dbg_only == 3) {
-            for (auto& f : L) f.fn(st, io);
-            c->last_set = p; c->frame_set = p ^ 1;
-            return 0;
-        }
         const uint32_t k = ++c->pipe_seq;
-        // the encoder phase overwrites the buffer set the decoder phase of frame k - 2 read
-        if (kern) { if (k > 2) launch_flag_wait(c->sig_dec, k - 2, c->enc_stream); }
-        else if (memops) { if (k > 2) HIPCHK(hipStreamWaitValue32(c->enc_stream, c->sig_dec, k - 2, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
-        else if (c->ev_dec_valid[p]) HIPCHK(hipStreamWaitEvent(c->enc_stream, c->ev_dec[p], 0));
-        if (src_ev) HIPCHK(hipStreamWaitEvent(c->enc_stream, src_ev, 0));
         int i0 = 0;
-        while (i0 < c->n_enc && L[i0].edge == 1) L[i0++].fn(c->enc_stream, io);        // the launch(es) that read src
-        if (!c->enc_exec[p] && !c->enc_graph_off && i0 < c->n_enc) {
-            const char* e = getenv("RVM_PIPE_GRAPH");
-            if (!(e && atoi(e) == 1)) c->enc_graph_off = true;   // measured no faster than eager launches (the host is not the bound): opt-in
-            else {
+        for (int j = 0; j < NE; ++j) {
+            hipStream_t es = c->enc_streams[j];
+            if (j == 0) {
+                if (kern) { if (k > (uint32_t)S) launch_flag_wait(c->sig_stage[NE], k - S, es); }
+                else if (c->ev_dec_valid[p]) HIPCHK(hipStreamWaitEvent(es, c->ev_stage[NE][p], 0));
+                if (src_ev) HIPCHK(hipStreamWaitEvent(es, src_ev, 0));
+            } else {
+                if (kern) launch_flag_wait(c->sig_stage[j - 1], k, es);
+                else HIPCHK(hipStreamWaitEvent(es, c->ev_stage[j - 1][p], 0));
+            }
+            while (i0 < c->stage_end[j] && L[i0].edge == 1) L[i0++].fn(es, io);         // the launch(es) that read src
+            hipGraphExec_t& ge = c->stage_exec[p][j];
+            if (!ge && !c->stage_graph_off && i0 < c->stage_end[j]) {
+                const char* e = getenv("RVM_PIPE_GRAPH");
+                if (e && atoi(e) == 0) c->stage_graph_off = true;
+                else {
+                    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+                    hipGraph_t graph = nullptr;
+                    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+                    for (int i = i0; i < c->stage_end[j]; ++i) L[i].fn(c->cap_stream, io);
+                    const hipError_t launch_err = hipGetLastError();
+                    const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);     // always ended: a stream left capturing poisons later calls
+                    hipError_t inst_err = hipErrorUnknown;
+                    if (launch_err == hipSuccess && end_err == hipSuccess && graph) inst_err = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    if (inst_err != hipSuccess) { ge = nullptr; c->stage_graph_off = true; (void)hipGetLastError(); }
+                }
+            }
+            if (ge) { HIPCHK(hipGraphLaunch(ge, es)); i0 = c->stage_end[j]; }
+            else for (; i0 < c->stage_end[j]; ++i0) L[i0].fn(es, io);
+            if (kern) launch_flag_set(c->sig_stage[j], k, es);
+            else HIPCHK(hipEventRecord(c->ev_stage[j][p], es));
+        }
+        if (kern) {
+            launch_flag_wait(c->sig_stage[NE - 1], k, st);
+            if (k > 1 && st != c->last_dec_stream) launch_flag_wait(c->sig_stage[NE], k - 1, st);      // (a caller that changes streams between frames)
+        } else {
+            HIPCHK(hipStreamWaitEvent(st, c->ev_stage[NE - 1][p], 0));
+            const int q = (p + S - 1) % S;
+            if (c->ev_dec_valid[q] && st != c->last_dec_stream) HIPCHK(hipStreamWaitEvent(st, c->ev_stage[NE][q], 0));
+        }
+        c->last_dec_stream = st;
+        if (c->graph_mode) {
+            // graph mode: the decoder phase up to the launch(es) that write fgr / pha replays as a HIP graph too, one per
+            // (state pointers, buffer set) - the caller keeps the states in a ring of static buffers (see rvm_set_graph_mode)
+            size_t hi = L.size();
+            while (hi > (size_t)c->n_enc && L[hi - 1].edge == 2) --hi;
+            FrameIO key = io; key.src = nullptr; key.fgr = nullptr; key.pha = nullptr;
+            key.u8 = nullptr; key.u8mode = 0; memset(key.bgr, 0, sizeof key.bgr);
+            key.seg |= (int64_t)(p + 1) << 32;
+            hipGraphExec_t exec = nullptr;
+            for (auto& g : c->graphs) if (g.key == key) { exec = g.exec; break; }
+            if (!exec) {
                 if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-                for (int i = i0; i < c->n_enc; ++i) L[i].fn(c->cap_stream, io);
+                for (size_t i = (size_t)c->n_enc; i < hi; ++i) L[i].fn(c->cap_stream, io);
                 const hipError_t launch_err = hipGetLastError();
-                const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);     // always ended: a stream left capturing poisons later calls
-                hipError_t inst_err = hipErrorUnknown;
-                if (launch_err == hipSuccess && end_err == hipSuccess && graph) inst_err = hipGraphInstantiate(&c->enc_exec[p], graph, nullptr, nullptr, 0);
-                if (graph) (void)hipGraphDestroy(graph);
-                if (inst_err != hipSuccess) { c->enc_exec[p] = nullptr; c->enc_graph_off = true; (void)hipGetLastError(); }
+                const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);
+                if (launch_err != hipSuccess || end_err != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    return fail(std::string("rvm_forward: graph capture failed: ") + hipGetErrorString(launch_err != hipSuccess ? launch_err : end_err));
+                }
+                const hipError_t inst_err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (inst_err != hipSuccess) return fail(std::string("rvm_forward: hipGraphInstantiate: ") + hipGetErrorString(inst_err));
+                if (c->graphs.size() >= 16) {
+                    const hipError_t sync_err = hipDeviceSynchronize();      // the evicted exec may still be running
+                    if (sync_err != hipSuccess) { (void)hipGraphExecDestroy(exec); return fail(std::string("rvm_forward: ") + hipGetErrorString(sync_err)); }
+                    (void)hipGraphExecDestroy(c->graphs.front().exec);
+                    c->graphs.erase(c->graphs.begin());
+                }
+                c->graphs.push_back({key, exec});
             }
-        }
-        if (dbg_only == 2) {}
-        else if (c->enc_exec[p]) HIPCHK(hipGraphLaunch(c->enc_exec[p], c->enc_stream));
-        else for (int i = i0; i < c->n_enc; ++i) L[i].fn(c->enc_stream, io);
-        // the decoder phase follows on the caller's stream
-        if (kern) {
-            launch_flag_set(c->sig_enc, k, c->enc_stream);
-            launch_flag_wait(c->sig_enc, k, st);
-            if (k > 1 && st != c->last_dec_stream) launch_flag_wait(c->sig_dec, k - 1, st);
-        } else if (memops) {
-            HIPCHK(hipStreamWriteValue32(c->enc_stream, c->sig_enc, k, 0));
-            HIPCHK(hipStreamWaitValue32(st, c->sig_enc, k, hipStreamWaitValueGte, 0xFFFFFFFFu));
-            if (k > 1 && st != c->last_dec_stream)           // (a caller that changes streams between frames)
-                HIPCHK(hipStreamWaitValue32(st, c->sig_dec, k - 1, hipStreamWaitValueGte, 0xFFFFFFFFu));
-        } else {
-            HIPCHK(hipEventRecord(c->ev_enc[p], c->enc_stream));
-            HIPCHK(hipStreamWaitEvent(st, c->ev_enc[p], 0));
-            if (c->ev_dec_valid[p ^ 1] && st != c->last_dec_stream) HIPCHK(hipStreamWaitEvent(st, c->ev_dec[p ^ 1], 0));
-        }
-        c->last_dec_stream = st;
-        for (size_t i = (size_t)c->n_enc; i < L.size(); ++i) if (dbg_only != 1 || i + 1 == L.size()) L[i].fn(st, io);
-        if (kern) launch_flag_set(c->sig_dec, k, st);
-        else if (memops) HIPCHK(hipStreamWriteValue32(st, c->sig_dec, k, 0));
-        else { HIPCHK(hipEventRecord(c->ev_dec[p], st)); c->ev_dec_valid[p] = true; }
-        c->last_set = p; c->frame_set = p ^ 1;
+            HIPCHK(hipGraphLaunch(exec, st));
+            for (size_t i = hi; i < L.size(); ++i) L[i].fn(st, io);
+        } else
+        for (size_t i = (size_t)c->n_enc; i < L.size(); ++i) L[i].fn(st, io);
+        if (kern) launch_flag_set(c->sig_stage[NE], k, st);
+        else { HIPCHK(hipEventRecord(c->ev_stage[NE][p], st)); c->ev_dec_valid[p] = true; }
+        c->last_set = p; c->frame_set = (p + 1) % S;
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -2257,7 +2295,7 @@ int rvm_debug_stamps(uint64_t* out, int capacity, int* nlaunch) {
 
 int rvm_debug_tap(rvm_ctx* c, const char* name, float* out, int64_t cap, int64_t shape[4]) {
     if (!c || !c->planned || !name) return fail("rvm_debug_tap: no plan");
-    auto& taps = (c->last_set && !c->taps_b.empty()) ? c->taps_b : c->taps;     // the buffer set of the last forward
+    auto& taps = (c->last_set > 0 && c->last_set <= (int)c->tap_sets.size()) ? c->tap_sets[c->last_set - 1] : c->taps;     // the buffer set of the last forward
     auto it = taps.find(name);
     if (it == taps.end()) return fail(std::string("rvm_debug_tap: unknown tap ") + name);
     const Tap& t = it->second;

@@ -173,7 +173,7 @@ class MattingNetwork(nn.Module):
         it is read on the context's stream, so it must be COMPLETE when forward is called (e.g. a frame uploaded and
         synchronised earlier, or produced on another stream) - or set `model.src_ready = event` (a recorded
         torch.cuda.Event, one-shot) before the call.  A src this wrapper has to copy first (non-contiguous) is ordered
-        automatically.  Ignored in graph mode."""
+        automatically.  With enable_graph() the decoder phase replays as a HIP graph as well (fewest host calls per frame)."""
         self._pipe = bool(on)
         if self._ctx is not None:
             self._ctx.set_frame_pipeline(self._pipe)
