@@ -250,7 +250,7 @@ def measure(a, wl_key, batch, chunk, steps, warmup, dev, rank, world, dist, dump
         res["fps_pipeline_off"] = n2 * batch * chunk / dt3
     dt2, _ = timed(n2, ring, sync_each=True, collective=False)
     res["fps_sync_every_frame"] = n2 * batch * chunk / dt2
-    if not pipe:
+    if not pipe and not a.one_schedule:
         schedule(True)
         dt3, _ = timed(n2, ring, collective=False)
         res["fps_pipeline_on"] = n2 * batch * chunk / dt3
@@ -415,6 +415,9 @@ def main():
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")
     ap.add_argument("--pipeline", default="on", choices=["on", "off"],
                     help="frame pipeline: the encoder phase of frame n+1 on a second stream beside the decoder phase of frame n")
+    ap.add_argument("--one-schedule", action="store_true",
+                    help="with --pipeline off: do not time the pipelined schedule either (profiler runs: every frame of the process "
+                         "is then the same sequence of launches on one stream)")
     ap.add_argument("--src-ring", type=int, default=0,
                     help="distinct step inputs cycled through (0: as many as exceed the 256 MiB Infinity Cache; 1: the same input every step)")
     ap.add_argument("--driver-pipeline", action="store_true", help="only the PCIe-inclusive convert_video rate of --workload")

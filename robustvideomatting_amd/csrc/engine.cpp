@@ -246,27 +246,27 @@ struct rvm_ctx {
     // per set: launches / taps are set 0's, launch_sets / tap_sets the others'.
     bool pipe_req = false;                              // what rvm_set_frame_pipeline asked for (plans built from now on)
     bool pipe = false;                                  // the active plan is (being) built for the pipeline
-    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 2; 1..3)
-    int stage_end[4] = {0, 0, 0, 0};                    // encoder stage j = launches [stage_end[j - 1], stage_end[j])
+    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 3; 1..4)
+    int stage_end[5] = {0, 0, 0, 0, 0};                 // encoder stage j = launches [stage_end[j - 1], stage_end[j])
     bool enc_phase = false;                             // build_plan: allocations and launches so far belong to the encoder phase
     size_t enc_shift = 0, enc_bytes = 0;                // build_plan: offset of the set being built; size of one set
     int n_enc = 0;                                      // launches [0, n_enc) are the encoder phase
     std::vector<std::vector<Launch>> launch_sets;
     std::vector<std::map<std::string, Tap>> tap_sets;
-    float* split_ws_enc = nullptr;                      // the encoder phase's own split-K workspace (the phases overlap)
+    float* split_ws_set[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the encoder stages' split-K workspace, one per buffer set (frames in flight overlap)
     int frame_set = 0, last_set = 0;                    // set of the next frame / of the last one (debug taps)
-    hipStream_t enc_streams[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_stage[4][4] = {};                     // [stage: encoder stages, then the decoder phase][set]
-    bool ev_dec_valid[4] = {false, false, false, false};
+    hipStream_t enc_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_stage[5][5] = {};                     // [stage: encoder stages, then the decoder phase][set]
+    bool ev_dec_valid[5] = {false, false, false, false, false};
     hipEvent_t src_event = nullptr;                     // one-shot: what the next frame's src waits for (null: src is complete)
-    unsigned* sig_stage[4] = {nullptr, nullptr, nullptr, nullptr};   // RVM_PIPE_SYNC=kernel: frame counters per stage
+    unsigned* sig_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // RVM_PIPE_SYNC=kernel: frame counters per stage
     uint32_t pipe_seq = 0;                              // frames sent through the pipeline; frame k's stages publish k
     int pipe_sync = 0;                                  // 0: undecided, 2: events, 3: flag kernels
     hipStream_t last_dec_stream = nullptr;
     // An encoder stage behind the launch that reads src touches neither src nor the states nor the outputs: one HIP graph
     // per (buffer set, stage), captured at the set's first frame.  With two encoder stages the host is the bound (46
     // launches, ~280 us of enqueueing per HD frame for ~210 us of device time); a frame then costs it ~16 launches.
-    hipGraphExec_t stage_exec[4][3] = {};               // [set][stage]
+    hipGraphExec_t stage_exec[5][4] = {};               // [set][stage]
     bool stage_graph_off = false;                       // capture failed once / RVM_PIPE_GRAPH=0: eager launches
 
     // graph mode
@@ -282,10 +282,10 @@ struct rvm_ctx {
         char* arena; size_t arena_bytes, arena_used;
         std::vector<Launch> launches; std::map<std::string, Tap> taps; std::map<std::string, int> tuned; std::vector<Tunable> tunable;
         float* split_ws; size_t split_need; std::vector<GraphEntry> graphs;
-        bool pipe = false; size_t enc_bytes = 0; int n_enc = 0, enc_stages = 1, stage_end[4] = {0, 0, 0, 0};
+        bool pipe = false; size_t enc_bytes = 0; int n_enc = 0, enc_stages = 1, stage_end[5] = {0, 0, 0, 0, 0};
         std::vector<std::vector<Launch>> launch_sets; std::vector<std::map<std::string, Tap>> tap_sets;
-        float* split_ws_enc = nullptr;
-        hipGraphExec_t stage_exec[4][3] = {};
+        float* split_ws_set[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipGraphExec_t stage_exec[5][4] = {};
     };
     std::vector<Parked> parked;                       // back = most recently used
     void swap_plan(Parked& p) {
@@ -296,10 +296,11 @@ struct rvm_ctx {
         launches.swap(p.launches); taps.swap(p.taps); tuned.swap(p.tuned); tunable.swap(p.tunable);
         std::swap(split_ws, p.split_ws); std::swap(split_need, p.split_need); graphs.swap(p.graphs);
         std::swap(pipe, p.pipe); std::swap(enc_bytes, p.enc_bytes); std::swap(n_enc, p.n_enc);
-        launch_sets.swap(p.launch_sets); tap_sets.swap(p.tap_sets); std::swap(split_ws_enc, p.split_ws_enc);
+        launch_sets.swap(p.launch_sets); tap_sets.swap(p.tap_sets);
+        for (int j = 0; j < 5; ++j) std::swap(split_ws_set[j], p.split_ws_set[j]);
         std::swap(enc_stages, p.enc_stages);
-        for (int j = 0; j < 4; ++j) std::swap(stage_end[j], p.stage_end[j]);
-        for (int a = 0; a < 4; ++a) for (int b = 0; b < 3; ++b) std::swap(stage_exec[a][b], p.stage_exec[a][b]);
+        for (int j = 0; j < 5; ++j) std::swap(stage_end[j], p.stage_end[j]);
+        for (int a = 0; a < 5; ++a) for (int b = 0; b < 4; ++b) std::swap(stage_exec[a][b], p.stage_exec[a][b]);
     }
     void free_parked() {
         for (auto& p : parked) {
@@ -879,12 +880,13 @@ int build_plan(rvm_ctx* c) {
                 c->split_need = std::max(c->split_need, (size_t)a.nsplit * B * HW * L.NT * 16 * sizeof(float));
             }
         }
-        const bool in_enc = c->enc_phase;                   // (frame pipeline: the phases have a split-K workspace each)
+        const bool in_enc = c->enc_phase;                   // (frame pipeline: every buffer set has a split-K workspace of its own)
+        const int ws_set = c->enc_bytes ? (int)(c->enc_shift / c->enc_bytes) : 0;
         add(name, 2.0 * B * HW * L.Cin * L.Cout,
             ((double)B * HW * (L.Cin + L.Cout + (res ? L.Cout : 0)) + (double)L.Cin * L.Cout) * es,
             [=](hipStream_t st, const FrameIO&) {
                 PwArgs b = a;
-                if (a.part) b.part = in_enc ? c->split_ws_enc : c->split_ws;
+                if (a.part) b.part = in_enc ? c->split_ws_set[ws_set] : c->split_ws;
                 launch_pw_m<T>(b, B, cfg, st, split);
             });
         if (a.part) c->launches.back().nk = 2;
@@ -1121,9 +1123,10 @@ int build_plan(rvm_ctx* c) {
         }
         const double KK = (double)L.KD * L.KD;
         const bool in_enc = c->enc_phase;
+        const int ws_set = c->enc_bytes ? (int)(c->enc_shift / c->enc_bytes) : 0;
         auto fn = [=](hipStream_t st, const FrameIO& io) {
             ConvArgs b = a; fill(b, io);
-            if (a.part) b.part = in_enc ? c->split_ws_enc : c->split_ws;
+            if (a.part) b.part = in_enc ? c->split_ws_set[ws_set] : c->split_ws;
             launch_conv3_m<T>(b, B, MW, NW, geo, st, split);
         };
         if (keep) { *keep = fn; return 0; }
@@ -1635,7 +1638,8 @@ int build_plan(rvm_ctx* c) {
         }
     }
     c->split_ws = c->split_need ? (float*)c->arena_alloc(c->split_need) : nullptr;
-    c->split_ws_enc = (c->pipe && c->split_need) ? (float*)c->arena_alloc(c->split_need) : c->split_ws;
+    for (int k = 0; k < 5; ++k)
+        c->split_ws_set[k] = (c->pipe && c->split_need && k <= c->enc_stages) ? (float*)c->arena_alloc(c->split_need) : c->split_ws;
     return plan_bad ? 1 : 0;
 }
 
@@ -1755,8 +1759,8 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     for (bool& v : c->ev_dec_valid) v = false;          // (a new arena: nothing in flight reads it)
     c->enc_stages = 1;
     if (c->pipe) {
-        const char* e = getenv("RVM_PIPE_STAGES");      // encoder stages (streams of the context's own): 1..3
-        c->enc_stages = e ? std::min(3, std::max(1, atoi(e))) : 2;
+        const char* e = getenv("RVM_PIPE_STAGES");      // encoder stages (streams of the context's own): 1..4
+        c->enc_stages = e ? std::min(4, std::max(1, atoi(e))) : 3;
     }
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
@@ -2020,7 +2024,9 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         const int NE = c->enc_stages, S = NE + 1, p = c->frame_set;
         auto& L = p ? c->launch_sets[p - 1] : c->launches;
         if (!c->enc_streams[0]) {
-            for (int j = 0; j < 3; ++j) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));
+            // (stream priorities make no difference: encoder streams at the lowest / highest priority measured 211.7 / 209.9 us
+            //  per HD frame against 210.0)
+            for (int j = 0; j < 4; ++j) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));
             // device-scope release is all the ordering needs (the default, release to system, also writes the L2 back)
             for (auto& row : c->ev_stage) for (auto& e : row) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
             // How the streams order each other.  Default: events.  RVM_PIPE_SYNC=kernel: a one-thread kernel publishes the

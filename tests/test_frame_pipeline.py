@@ -57,7 +57,7 @@ def _same(a, b):
 def test_pipelined_frames_are_bit_identical(dtype, variant, H, W, ds, B):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    T = 24
+    T = 40
     clip = _clip(T, H, W, dtype, B=B)
     torch.cuda.synchronize()
     m = _model(dtype, variant)

@@ -10,7 +10,7 @@ cd /tmp
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -s KILL 170 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_$TAG/p$i -- python3 $R/bench.py --steps 12 --warmup 4 --mode eager --workload ${WL:-hd} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --no-also --dump-kernels $R/gpurun_out/pmc_$TAG/kernels.json > $R/gpurun_out/pmc_$TAG/stdout_$i.txt 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_$TAG/stdout_$i.txt; exit 1; }
+  timeout -s KILL 170 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_$TAG/p$i -- python3 $R/bench.py --steps 12 --warmup 4 --pipeline off --one-schedule --mode eager --workload ${WL:-hd} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --no-also --dump-kernels $R/gpurun_out/pmc_$TAG/kernels.json > $R/gpurun_out/pmc_$TAG/stdout_$i.txt 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_$TAG/stdout_$i.txt; exit 1; }
 done
 cd $R
 python3 tools/pmc_table.py gpurun_out/pmc_$TAG gpurun_out/pmc_$TAG/kernels.json > gpurun_out/pmc_${TAG}_table.txt 2>&1

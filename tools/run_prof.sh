@@ -5,7 +5,7 @@ TAG=${TAG:-hd}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --mode ${MODE:-eager} --workload ${WL:-hd} --dtype ${DT:-fp16} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --no-also --dump-kernels $R/gpurun_out/prof_${TAG}_kernels.json > $R/gpurun_out/prof_${TAG}_stdout.txt 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --pipeline off --one-schedule --mode ${MODE:-eager} --workload ${WL:-hd} --dtype ${DT:-fp16} --batch ${BATCH:-1} --chunk ${CHUNK:-1} --no-cpu-baseline --no-also --dump-kernels $R/gpurun_out/prof_${TAG}_kernels.json > $R/gpurun_out/prof_${TAG}_stdout.txt 2>&1
 echo exit=$?
 cd $R
 f=$(ls gpurun_out/prof_$TAG/*/*kernel_trace.csv | head -1)
