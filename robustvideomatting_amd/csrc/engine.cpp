@@ -246,7 +246,7 @@ struct rvm_ctx {
     // per set: launches / taps are set 0's, launch_sets / tap_sets the others'.
     bool pipe_req = false;                              // what rvm_set_frame_pipeline asked for (plans built from now on)
     bool pipe = false;                                  // the active plan is (being) built for the pipeline
-    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 3; 1..4)
+    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 2; 1..4)
     int stage_end[5] = {0, 0, 0, 0, 0};                 // encoder stage j = launches [stage_end[j - 1], stage_end[j])
     bool enc_phase = false;                             // build_plan: allocations and launches so far belong to the encoder phase
     size_t enc_shift = 0, enc_bytes = 0;                // build_plan: offset of the set being built; size of one set
@@ -1760,7 +1760,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     c->enc_stages = 1;
     if (c->pipe) {
         const char* e = getenv("RVM_PIPE_STAGES");      // encoder stages (streams of the context's own): 1..4
-        c->enc_stages = e ? std::min(4, std::max(1, atoi(e))) : 3;
+        c->enc_stages = e ? std::min(4, std::max(1, atoi(e))) : 2;
     }
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
@@ -2023,10 +2023,11 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         // decoder phase, on the caller's stream, for the last encoder stage.
         const int NE = c->enc_stages, S = NE + 1, p = c->frame_set;
         auto& L = p ? c->launch_sets[p - 1] : c->launches;
-        if (!c->enc_streams[0]) {
+        for (int j = 0; j < NE; ++j)                        // only as many streams as stages: the device has GPU_MAX_HW_QUEUES (4) hardware
+            if (!c->enc_streams[j]) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));   // queues, and two streams on one queue take turns
+        if (!c->pipe_sync) {
             // (stream priorities make no difference: encoder streams at the lowest / highest priority measured 211.7 / 209.9 us
             //  per HD frame against 210.0)
-            for (int j = 0; j < 4; ++j) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));
             // device-scope release is all the ordering needs (the default, release to system, also writes the L2 back)
             for (auto& row : c->ev_stage) for (auto& e : row) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
             // How the streams order each other.  Default: events.  RVM_PIPE_SYNC=kernel: a one-thread kernel publishes the
@@ -2067,12 +2068,13 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
                 const char* e = getenv("RVM_PIPE_GRAPH");
                 if (e && atoi(e) == 0) c->stage_graph_off = true;
                 else {
-                    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+                    // captured on the stage's own stream (no further stream: see above); what is already enqueued on it stays
+                    // outside the capture
                     hipGraph_t graph = nullptr;
-                    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-                    for (int i = i0; i < c->stage_end[j]; ++i) L[i].fn(c->cap_stream, io);
+                    HIPCHK(hipStreamBeginCapture(es, hipStreamCaptureModeThreadLocal));
+                    for (int i = i0; i < c->stage_end[j]; ++i) L[i].fn(es, io);
                     const hipError_t launch_err = hipGetLastError();
-                    const hipError_t end_err = hipStreamEndCapture(c->cap_stream, &graph);     // always ended: a stream left capturing poisons later calls
+                    const hipError_t end_err = hipStreamEndCapture(es, &graph);     // always ended: a stream left capturing poisons later calls
                     hipError_t inst_err = hipErrorUnknown;
                     if (launch_err == hipSuccess && end_err == hipSuccess && graph) inst_err = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
                     if (graph) (void)hipGraphDestroy(graph);
