@@ -144,7 +144,7 @@ class MattingNetwork(nn.Module):
         ``edit_check_interval``-th call (default 64; 1 = every call, ~40 us of host time) under ``torch.no_grad()``, the
         inference loop - so up to 63 frames may still use the old weights; call ``refresh()`` right after an edit to
         re-pack at once.  Writes through ``p.data.copy_()`` bump no counter at all - ``refresh()`` is the only way."""
-        self._calls += 1
+        object.__setattr__(self, "_calls", self._calls + 1)      # (nn.Module.__setattr__ costs ~2.5 us a write: this is the frame path)
         if self._dirty or self._live_sig is None:
             return
         if not torch.is_grad_enabled() and (self._calls % max(1, int(self.edit_check_interval))):
@@ -182,11 +182,13 @@ class MattingNetwork(nn.Module):
     def _order_src(self, ctx, dev, copied):
         if not self._pipe:
             return
-        ev, self.src_ready = self.src_ready, None
+        ev = self.src_ready
+        if ev is not None:
+            object.__setattr__(self, "src_ready", None)
         if copied:                                  # produced on the current stream a moment ago
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-        self._src_ev_hold = ev                      # the native side takes the raw handle: keep the event alive through the call
+        object.__setattr__(self, "_src_ev_hold", ev)    # the native side takes the raw handle: keep the event alive through the call
         if ev is not None:
             ctx.src_event(ev.cuda_event)
 
@@ -285,7 +287,7 @@ class MattingNetwork(nn.Module):
         H, W = src.shape[-2:]
         chunk = five and T > 1 and self.chunk_batching
         ctx.plan(B, H, W, ds, T if chunk else 1)
-        shapes = [ctx.state_shape(l) for l in (1, 2, 3, 4)]
+        shapes = ctx.state_shapes()
         dev, dt = src.device, src.dtype
 
         rec = list(rec)

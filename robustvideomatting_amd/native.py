@@ -164,6 +164,8 @@ class Context:
         check(L.rvm_create(VARIANTS[variant], REFINERS[refiner], dtype_code, device_index,
                            ctypes.byref(self._h)), "rvm_create")
         self.plan_key = None
+        self._shapes, self._shapes_key = None, ()
+        self._rin, self._rout = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -216,9 +218,18 @@ class Context:
         check(lib().rvm_state_shape(self._h, level, shape), "rvm_state_shape")
         return tuple(shape[k] for k in range(4))
 
+    def state_shapes(self):
+        """Shapes of r1..r4 for the current plan (cached per plan: four ABI calls otherwise, on every frame)."""
+        if self._shapes_key != self.plan_key:
+            self._shapes = [self.state_shape(l) for l in (1, 2, 3, 4)]
+            self._shapes_key = self.plan_key
+        return self._shapes
+
     def forward(self, src_ptr, r_in_ptrs, fgr_ptr, pha_ptr, r_out_ptrs, seg, stream):
-        rin = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) if p else None for p in r_in_ptrs])
-        rout = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) for p in r_out_ptrs])
+        rin, rout = self._rin, self._rout                   # (reused: building two ctypes arrays costs ~6 us a frame)
+        for i in range(4):
+            rin[i] = r_in_ptrs[i] or None
+            rout[i] = r_out_ptrs[i]
         check(lib().rvm_forward(self._h, ctypes.c_void_p(src_ptr), rin,
                                 ctypes.c_void_p(fgr_ptr) if fgr_ptr else None, ctypes.c_void_p(pha_ptr),
                                 rout, 1 if seg else 0, ctypes.c_void_p(stream)), "rvm_forward")
