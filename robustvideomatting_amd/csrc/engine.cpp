@@ -2021,7 +2021,7 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         // Frame pipeline: encoder stage 0 waits for the decoder phase that last read this buffer set (sets = stages in
         // flight) and for src's event if one was given; every later stage waits for the one before it on this frame; the
         // decoder phase, on the caller's stream, for the last encoder stage.
-        const int NE = c->enc_stages, S = NE + 1, p = c->frame_set;
+        const int NE = c->enc_stages, S = NE + 1, p = c->frame_set % S;      // (% S: the plan before this one may have had more sets)
         auto& L = p ? c->launch_sets[p - 1] : c->launches;
         for (int j = 0; j < NE; ++j)                        // only as many streams as stages: the device has GPU_MAX_HW_QUEUES (4) hardware
             if (!c->enc_streams[j]) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));   // queues, and two streams on one queue take turns

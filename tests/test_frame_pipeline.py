@@ -159,3 +159,33 @@ def test_src_event_orders_a_source_produced_on_another_stream():
             got.append([x.clone() for x in o])
     torch.cuda.synchronize()
     _same(want, got)
+
+
+def test_two_shapes_interleaved_through_one_pipelined_module():
+    """Two streams of different frame sizes take turns on one module: every call switches the plan (the plan cache parks the
+    other one, its frames still in flight on its own arena) - and the buffer-set counter runs on across the switches."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dtype = torch.float16
+    a = [f.contiguous() for f in _clip(12, 540, 960, dtype, seed=1).unbind(1)]
+    b = [f.contiguous() for f in _clip(12, 270, 482, dtype, B=2, seed=2).unbind(1)]
+    torch.cuda.synchronize()
+    m = _model(dtype)
+
+    def run():
+        ra, rb = [None] * 4, [None] * 4
+        outs = []
+        with torch.no_grad():
+            for fa, fb in zip(a, b):
+                oa = m(fa, None, *ra, 0.25)
+                ra = oa[2:]
+                ob = m(fb, None, *rb, 0.5)
+                rb = ob[2:]
+                outs.append([x.clone() for x in oa] + [x.clone() for x in ob])
+        torch.cuda.synchronize()
+        return outs
+
+    want = run()
+    m.pipeline_frames(True)
+    _same(want, run())
+    _same(want, run())
