@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout -k 10 400 python -u tools/r3_dgf.py > gpurun_out/q_dgf.txt 2>&1 || { tail -30 gpurun_out/q_dgf.txt; exit 1; }
+timeout -k 10 400 python -u tools/dgf_apply_times.py > gpurun_out/q_dgf.txt 2>&1 || { tail -30 gpurun_out/q_dgf.txt; exit 1; }
 tail -1 gpurun_out/q_dgf.txt
 for cfg in "hd --batch 8 --steps 60" "4k --steps 100" "hd --steps 200"; do
 set -- $cfg; wl=$1; shift

@@ -1,4 +1,4 @@
-# Frame pipeline: its tests, then the bench line with the pipeline off / on (WL as in tools/r3_now.sh).
+# Frame pipeline: its tests, then the bench line with the pipeline off / on (WL as in tools/launch_times.sh).
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests/test_frame_pipeline.py -x -v --timeout 300 --timeout-method thread > gpurun_out/pipe_pytest.txt 2>&1 || { tail -40 gpurun_out/pipe_pytest.txt; exit 1; }
 tail -12 gpurun_out/pipe_pytest.txt

@@ -1,4 +1,4 @@
-# Frame pipeline: encoder stages 1 / 2 / 3 on the bench workloads (WL as in tools/r3_now.sh).
+# Frame pipeline: encoder stages 1 / 2 / 3 on the bench workloads (WL as in tools/launch_times.sh).
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for wl in ${WL:-hd 4k b8 rn}; do
 case $wl in
