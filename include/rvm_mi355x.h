@@ -166,16 +166,19 @@ int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
 /* Frame pipeline (no counterpart in the reference, whose ATen launches all go to one stream; for callers that send frames
  * without waiting for the previous one, e.g. reference inference.py:122-141 with a device-side writer).
  * The encoder phase of a frame - downsample, backbone, LR-ASPP (model/model.py:52-58) - does not depend on the recurrent
- * state, so with the pipeline on it runs on a stream of the context's own, BESIDE the decoder / refiner phase
- * (model/model.py:59-67) of the frame before, which stays on the caller's stream.  Results are bit-identical; fgr / pha /
- * r_out are ordered on the caller's stream as always.  What changes is the contract for `src`: the encoder reads it on
- * the context's stream, so it must be complete when rvm_forward is called - or ordered behind the HIP event handed to
+ * state, so with the pipeline on it is cut into stages (RVM_PIPE_STAGES, default 2) that run on streams of the context's
+ * own, BESIDE the decoder / refiner phase (model/model.py:59-67) of the frames before, which stays on the caller's stream:
+ * stages + 1 frames are in flight.  Results are bit-identical; fgr / pha / r_out are ordered on the caller's stream as
+ * always, and so must r_in be.  What changes is the contract for `src`: the first stage reads it on the context's stream,
+ * so it must be complete when rvm_forward is called - or ordered behind the HIP event handed to
  * rvm_frame_pipeline_src_event just before that call (one-shot; e.g. the event of the upload that fills src).  src must
  * stay untouched until work enqueued after the call on `hip_stream` could touch it (stream order on `hip_stream` is
- * enough: the decoder phase waits for the encoder phase).  The setting applies to plans made from then on: call
- * rvm_plan / rvm_plan_seq again after changing it.  Costs one more set of the encoder's buffers in the arena
- * (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  In graph mode (rvm_set_graph_mode) the decoder phase
- * replays as a HIP graph as well, one per (state pointers, buffer set). 0 = off (default). */
+ * enough: the decoder phase waits for the encoder stages).  Not for callers that capture rvm_forward into a graph of their
+ * own (the call enqueues on several streams).  The setting applies to plans made from then on: call
+ * rvm_plan / rvm_plan_seq again after changing it (a context keeps plans of both kinds).  Costs one more set of the
+ * encoder's buffers per stage in the arena (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  In graph
+ * mode (rvm_set_graph_mode) the decoder phase replays as a HIP graph as well, one per (state pointers, buffer set).
+ * 0 = off (default). */
 int rvm_set_frame_pipeline(rvm_ctx* ctx, int enabled);
 int rvm_frame_pipeline_src_event(rvm_ctx* ctx, void* hip_event);
 
