@@ -166,7 +166,7 @@ int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
 /* Frame pipeline (no counterpart in the reference, whose ATen launches all go to one stream; for callers that send frames
  * without waiting for the previous one, e.g. reference inference.py:122-141 with a device-side writer).
  * The encoder phase of a frame - downsample, backbone, LR-ASPP (model/model.py:52-58) - does not depend on the recurrent
- * state, so with the pipeline on it is cut into stages (RVM_PIPE_STAGES, default 2) that run on streams of the context's
+ * state, so with the pipeline on it is cut into stages (RVM_PIPE_STAGES, default 3) that run on streams of the context's
  * own, BESIDE the decoder / refiner phase (model/model.py:59-67) of the frames before, which stays on the caller's stream:
  * stages + 1 frames are in flight.  Results are bit-identical; fgr / pha / r_out are ordered on the caller's stream as
  * always, and so must r_in be.  What changes is the contract for `src`: the first stage reads it on the context's stream,

@@ -268,6 +268,7 @@ template <typename T> void launch_down(const DownArgs& a, int N, int io, hipStre
 void launch_state_prep(const StatePrep& sp, int io, hipStream_t s);   // io: IO_F16 / IO_BF16
 void launch_flag_set(unsigned* flag, unsigned k, hipStream_t s);          // frame pipeline: counter-in-memory ordering between its streams
 void launch_flag_wait(const unsigned* flag, unsigned k, hipStream_t s);
+void launch_queue_probe(unsigned long long* out, unsigned ticks, hipStream_t s);   // out[0], out[1]: begin / end on the 100 MHz wall clock
 template <typename T> void launch_dgf_low(const DgfLowArgs& a, int N, hipStream_t s);
 template <typename T> void launch_dgf_apply(const DgfApplyArgs& a, int N, int io, hipStream_t s);
 void dgf_apply_pick(DgfApplyArgs& a);                           // sets kx / rows from the geometry

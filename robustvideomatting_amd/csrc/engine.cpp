@@ -246,7 +246,7 @@ struct rvm_ctx {
     // per set: launches / taps are set 0's, launch_sets / tap_sets the others'.
     bool pipe_req = false;                              // what rvm_set_frame_pipeline asked for (plans built from now on)
     bool pipe = false;                                  // the active plan is (being) built for the pipeline
-    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 2; 1..4)
+    int enc_stages = 1;                                 // of the active plan (RVM_PIPE_STAGES, default 3; 1..4)
     int stage_end[5] = {0, 0, 0, 0, 0};                 // encoder stage j = launches [stage_end[j - 1], stage_end[j])
     bool enc_phase = false;                             // build_plan: allocations and launches so far belong to the encoder phase
     size_t enc_shift = 0, enc_bytes = 0;                // build_plan: offset of the set being built; size of one set
@@ -1760,7 +1760,7 @@ int plan_impl(rvm_ctx* c, int B, int T, int H, int W, double ds) {
     c->enc_stages = 1;
     if (c->pipe) {
         const char* e = getenv("RVM_PIPE_STAGES");      // encoder stages (streams of the context's own): 1..4
-        c->enc_stages = e ? std::min(4, std::max(1, atoi(e))) : 2;
+        c->enc_stages = e ? std::min(4, std::max(1, atoi(e))) : 3;
     }
     if (ds == 1.0) { c->h = H; c->w = W; }
     else { c->h = (int)std::floor((double)H * ds); c->w = (int)std::floor((double)W * ds); }
@@ -1871,7 +1871,11 @@ void rvm_destroy(rvm_ctx* c) {
     (void)hipDeviceSynchronize();          // graphs / arena may still be in flight on the caller's streams
     c->drop_graphs();
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-    for (auto& e : c->enc_streams) if (e) (void)hipStreamDestroy(e);
+    for (int j = 0; j < 4; ++j) {
+        bool dup = false;
+        for (int i = 0; i < j; ++i) dup |= c->enc_streams[i] == c->enc_streams[j];
+        if (c->enc_streams[j] && !dup) (void)hipStreamDestroy(c->enc_streams[j]);
+    }
     for (auto& g : c->sig_stage) if (g) (void)hipFree(g);
     for (auto& row : c->ev_stage) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (c->wdev) (void)hipFree(c->wdev);
@@ -2006,6 +2010,60 @@ int rvm_forward_u8(rvm_ctx* c, const void* src, const void* const r_in[4], uint8
     return forward_impl(c, io, r_in, r_out, hip_stream);
 }
 
+// Streams for the encoder stages of the frame pipeline.  A stream is bound to one of the device's hardware queues
+// (GPU_MAX_HW_QUEUES, 4 here) in the order the process creates its streams, and two streams on one queue take turns: measured
+// on the HD frame, two stages 4750 frames/s on queues of their own and 3005 when one of them shares the caller's queue; three
+// stages 5100-5380 against 3650-4000.  Which queue a new stream gets depends on how many streams the process made before, so
+// it is found out: candidates are created one by one and each is kept only if a probe kernel on it overlaps in time with
+// probes on the caller's stream and on every stream kept so far.  One-time, ~1 ms; the probes on the caller's stream are
+// ordinary stream-ordered work.  If fewer than `need` independent queues turn up, the stages share the streams found.
+static int pick_stage_streams(rvm_ctx* c, hipStream_t st, int need) {
+    int have = 0;
+    while (have < 4 && c->enc_streams[have]) ++have;
+    if (have >= need) return 0;
+    if (const char* e = getenv("RVM_PIPE_DUMMY")) {          // measurement hook: n streams made (and used) first, as an application might have
+        static std::vector<hipStream_t> dummies;
+        for (int k = (int)dummies.size(); k < atoi(e) && k < 8; ++k) {
+            hipStream_t d = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+            HIPCHK(hipMemsetAsync(c->arena, 0, 4, d));
+            HIPCHK(hipStreamSynchronize(d));
+            dummies.push_back(d);
+        }
+    }
+    unsigned long long* ts = nullptr;
+    HIPCHK(hipMalloc((void**)&ts, 16 * sizeof(unsigned long long)));
+    const unsigned ticks = 4000;                             // 40 us
+    const bool probe = !(getenv("RVM_PIPE_PROBE") && atoi(getenv("RVM_PIPE_PROBE")) == 0);
+    std::vector<hipStream_t> rejected;
+    for (int tries = 0; have < need && tries < 8; ++tries) {
+        hipStream_t cand = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+        bool ok = true;
+        if (probe) {
+            HIPCHK(hipDeviceSynchronize());
+            launch_queue_probe(ts, ticks, st);
+            for (int j = 0; j < have; ++j) launch_queue_probe(ts + 2 * (j + 1), ticks, c->enc_streams[j]);
+            launch_queue_probe(ts + 2 * (have + 1), ticks, cand);
+            HIPCHK(hipDeviceSynchronize());
+            unsigned long long h[16];
+            HIPCHK(hipMemcpy(h, ts, sizeof h, hipMemcpyDeviceToHost));
+            const unsigned long long cb = h[2 * (have + 1)], ce = h[2 * (have + 1) + 1];
+            for (int j = 0; j <= have; ++j) {                // overlaps every other probe by at least a quarter of its length?
+                const unsigned long long b = std::max(cb, h[2 * j]), e = std::min(ce, h[2 * j + 1]);
+                if (e < b + ticks / 4) ok = false;
+            }
+        }
+        if (ok) c->enc_streams[have++] = cand; else rejected.push_back(cand);
+    }
+    (void)hipFree(ts);
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: %d of %d stage streams on queues of their own (%zu candidates shared a queue)\n", have, need, rejected.size());
+    if (have == 0) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[have++], hipStreamNonBlocking));
+    for (int j = have; j < need; ++j) c->enc_streams[j] = c->enc_streams[j % have];     // shared: those stages take turns
+    return 0;
+}
+
 static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void* const r_out[4], void* hip_stream) {
     for (int i = 0; i < 4; ++i) {
         io.r_in[i] = r_in ? r_in[i] : nullptr;
@@ -2023,8 +2081,7 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         // decoder phase, on the caller's stream, for the last encoder stage.
         const int NE = c->enc_stages, S = NE + 1, p = c->frame_set % S;      // (% S: the plan before this one may have had more sets)
         auto& L = p ? c->launch_sets[p - 1] : c->launches;
-        for (int j = 0; j < NE; ++j)                        // only as many streams as stages: the device has GPU_MAX_HW_QUEUES (4) hardware
-            if (!c->enc_streams[j]) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[j], hipStreamNonBlocking));   // queues, and two streams on one queue take turns
+        if (!c->enc_streams[NE - 1]) { const int rc = pick_stage_streams(c, st, NE); if (rc) return rc; }
         if (!c->pipe_sync) {
             // (stream priorities make no difference: encoder streams at the lowest / highest priority measured 211.7 / 209.9 us
             //  per HD frame against 210.0)

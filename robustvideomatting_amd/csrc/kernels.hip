@@ -1905,6 +1905,16 @@ __global__ __launch_bounds__(64) void flag_wait(const unsigned* flag, unsigned k
         if (wall_clock64() - t0 > 200000000ull) break;                // 100 MHz counter
     }
 }
+// Frame pipeline: which streams really run side by side?  A stream is bound to one of the device's few hardware queues
+// (GPU_MAX_HW_QUEUES = 4, handed out in turn), and two streams on one queue take turns.  queue_probe occupies its stream for
+// `ticks` of the 100 MHz wall clock and reports when it ran; the host launches one on each stream in question and compares.
+__global__ __launch_bounds__(64) void queue_probe(unsigned long long* out, unsigned ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    out[0] = t0; out[1] = wall_clock64();
+}
+void launch_queue_probe(unsigned long long* out, unsigned ticks, hipStream_t s) { hipLaunchKernelGGL(queue_probe, dim3(1), dim3(64), 0, s, out, ticks); }
 void launch_flag_set(unsigned* flag, unsigned k, hipStream_t s) { hipLaunchKernelGGL(flag_set, dim3(1), dim3(64), 0, s, flag, k); }
 void launch_flag_wait(const unsigned* flag, unsigned k, hipStream_t s) { hipLaunchKernelGGL(flag_wait, dim3(1), dim3(64), 0, s, flag, k); }
 template void launch_down<f16>(const DownArgs&, int, int, hipStream_t);
