@@ -74,6 +74,31 @@ def test_pipelined_frames_are_bit_identical(dtype, variant, H, W, ds, B):
     _same(want, _run(m, clip, ds, sync_every_frame=False))
 
 
+@pytest.mark.parametrize("dtype,H,W,ds,B", [
+    (torch.float16, 1080, 1920, 0.25, 1),
+    (torch.float32, 122, 218, 0.25, 2),
+])
+def test_pipelined_graph_mode_is_bit_identical(dtype, H, W, ds, B):
+    """enable_graph() with the pipeline: the decoder phase replays as one graph per (buffer set, state-ring position) beside
+    the stage graphs - the same bits as eager launches on one stream, through more frames than the graph cache has entries."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    T = 40
+    clip = _clip(T, H, W, dtype, B=B)
+    torch.cuda.synchronize()
+    m = _model(dtype)
+    want = _run(m, clip, ds, sync_every_frame=True)
+    m.enable_graph(True)
+    m.pipeline_frames(True)
+    _same(want, _run(m, clip, ds, sync_every_frame=False))
+    _same(want, _run(m, clip, ds, sync_every_frame=False))         # replays only
+    m.pipeline_frames(False)                                       # graph mode on one stream, same module
+    _same(want, _run(m, clip, ds, sync_every_frame=False))
+    m.enable_graph(False)
+    m.pipeline_frames(True)
+    _same(want, _run(m, clip, ds, sync_every_frame=False))
+
+
 def test_pipelined_debug_taps_follow_the_buffer_set():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
