@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "../../include/rvm_mi355x.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -256,6 +257,8 @@ struct rvm_ctx {
     float* split_ws_set[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the encoder stages' split-K workspace, one per buffer set (frames in flight overlap)
     int frame_set = 0, last_set = 0;                    // set of the next frame / of the last one (debug taps)
     hipStream_t enc_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipStream_t> probed_streams;            // caller's streams the stage streams were probed against (pick_stage_streams)
+    int stream_picks = 0, stream_prio = 0;              // probing rounds so far; priority of the stage streams (the caller's)
     hipEvent_t ev_stage[5][5] = {};                     // [stage: encoder stages, then the decoder phase][set]
     bool ev_dec_valid[5] = {false, false, false, false, false};
     hipEvent_t src_event = nullptr;                     // one-shot: what the next frame's src waits for (null: src is complete)
@@ -2015,12 +2018,27 @@ int rvm_forward_u8(rvm_ctx* c, const void* src, const void* const r_in[4], uint8
 // on the HD frame, two stages 4750 frames/s on queues of their own and 3005 when one of them shares the caller's queue; three
 // stages 5100-5380 against 3650-4000.  Which queue a new stream gets depends on how many streams the process made before, so
 // it is found out: candidates are created one by one and each is kept only if a probe kernel on it overlaps in time with
-// probes on the caller's stream and on every stream kept so far.  One-time, ~1 ms; the probes on the caller's stream are
-// ordinary stream-ordered work.  If fewer than `need` independent queues turn up, the stages share the streams found.
+// probes on the caller's stream and on every stream kept so far.  ~1 ms; the probes on the caller's stream are ordinary
+// stream-ordered work.  If fewer than `need` independent queues turn up, the stages share the streams found.
+// A caller's stream the kept ones were not probed against (the caller went over to another stream) gets the same treatment:
+// the kept streams that share ITS queue are given up (the device is idle at that point) and replaced; measured with the
+// module moved from the default stream to a torch.cuda.Stream(): 273 us per HD frame before this, against 197.  At most
+// eight such rounds per context (caller's streams in turn, more streams than queues: there is no arrangement to find);
+// a change of the caller's priority is followed every time.
 static int pick_stage_streams(rvm_ctx* c, hipStream_t st, int need) {
-    int have = 0;
-    while (have < 4 && c->enc_streams[have]) ++have;
-    if (have >= need) return 0;
+    const bool seen = std::find(c->probed_streams.begin(), c->probed_streams.end(), st) != c->probed_streams.end();
+    if (c->enc_streams[need - 1] && seen) return 0;          // (every frame comes through here)
+    // The stage streams take the priority of the caller's stream: the decoder phase on a high-priority stream waiting for
+    // stages on normal-priority ones hung the device-side queues (a caller on torch.cuda.Stream(priority=-1) after three
+    // callers on ordinary streams: the frames never completed; tools/pipe_stream_switch.py).
+    int prio = 0;
+    if (hipStreamGetPriority(st, &prio) != hipSuccess) { prio = 0; (void)hipGetLastError(); }
+    if (c->enc_streams[need - 1] && c->stream_picks >= 8 && prio == c->stream_prio) return 0;
+    const bool probe = !(getenv("RVM_PIPE_PROBE") && atoi(getenv("RVM_PIPE_PROBE")) == 0);
+    std::vector<hipStream_t> own;                            // distinct streams of the context's own, in stage order
+    for (int j = 0; j < 4; ++j)
+        if (c->enc_streams[j] && std::find(own.begin(), own.end(), c->enc_streams[j]) == own.end()) own.push_back(c->enc_streams[j]);
+    const size_t had = own.size();
     if (const char* e = getenv("RVM_PIPE_DUMMY")) {          // measurement hook: n streams made (and used) first, as an application might have
         static std::vector<hipStream_t> dummies;
         for (int k = (int)dummies.size(); k < atoi(e) && k < 8; ++k) {
@@ -2034,33 +2052,59 @@ static int pick_stage_streams(rvm_ctx* c, hipStream_t st, int need) {
     unsigned long long* ts = nullptr;
     HIPCHK(hipMalloc((void**)&ts, 16 * sizeof(unsigned long long)));
     const unsigned ticks = 4000;                             // 40 us
-    const bool probe = !(getenv("RVM_PIPE_PROBE") && atoi(getenv("RVM_PIPE_PROBE")) == 0);
     std::vector<hipStream_t> rejected;
-    for (int tries = 0; have < need && tries < 8; ++tries) {
+    unsigned long long h[16];
+    // one round of probes: the caller's stream (slot 0), the kept streams, the candidate if there is one (last slot)
+    auto round = [&](hipStream_t cand) -> int {
+        HIPCHK(hipDeviceSynchronize());
+        launch_queue_probe(ts, ticks, st);
+        for (size_t j = 0; j < own.size(); ++j) launch_queue_probe(ts + 2 * (j + 1), ticks, own[j]);
+        if (cand) launch_queue_probe(ts + 2 * (own.size() + 1), ticks, cand);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(h, ts, sizeof h, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    auto overlap = [&](size_t x, size_t y) {                 // by at least a quarter of a probe's length?
+        const unsigned long long b = std::max(h[2 * x], h[2 * y]), e = std::min(h[2 * x + 1], h[2 * y + 1]);
+        return e >= b + ticks / 4;
+    };
+    if (!own.empty() && prio != c->stream_prio) {           // all of them are replaced
+        HIPCHK(hipDeviceSynchronize());
+        rejected.swap(own);
+    }
+    c->stream_prio = prio;
+    if (probe && !own.empty() && !seen) {                    // a new caller's stream: which of the kept ones sit on its queue?
+        if (round(nullptr)) { (void)hipFree(ts); return -1; }
+        std::vector<hipStream_t> keep;
+        for (size_t j = 0; j < own.size(); ++j) (overlap(0, j + 1) ? keep : rejected).push_back(own[j]);
+        own.swap(keep);
+        if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: caller's stream %p: %zu of %zu stage streams share its queue\n", (void*)st, had - own.size(), had);
+    }
+    const size_t dropped = had - own.size();
+    for (int tries = 0; (int)own.size() < need && tries < 8; ++tries) {
         hipStream_t cand = nullptr;
-        HIPCHK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio));
         bool ok = true;
         if (probe) {
-            HIPCHK(hipDeviceSynchronize());
-            launch_queue_probe(ts, ticks, st);
-            for (int j = 0; j < have; ++j) launch_queue_probe(ts + 2 * (j + 1), ticks, c->enc_streams[j]);
-            launch_queue_probe(ts + 2 * (have + 1), ticks, cand);
-            HIPCHK(hipDeviceSynchronize());
-            unsigned long long h[16];
-            HIPCHK(hipMemcpy(h, ts, sizeof h, hipMemcpyDeviceToHost));
-            const unsigned long long cb = h[2 * (have + 1)], ce = h[2 * (have + 1) + 1];
-            for (int j = 0; j <= have; ++j) {                // overlaps every other probe by at least a quarter of its length?
-                const unsigned long long b = std::max(cb, h[2 * j]), e = std::min(ce, h[2 * j + 1]);
-                if (e < b + ticks / 4) ok = false;
-            }
+            if (round(cand)) { (void)hipFree(ts); return -1; }
+            for (size_t j = 0; j <= own.size(); ++j) ok &= overlap(own.size() + 1, j);
         }
-        if (ok) c->enc_streams[have++] = cand; else rejected.push_back(cand);
+        if (ok) own.push_back(cand); else rejected.push_back(cand);
+        if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: candidate %d %s\n", tries, ok ? "kept" : "shares a queue");
     }
     (void)hipFree(ts);
     for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: %d of %d stage streams on queues of their own (%zu candidates shared a queue)\n", have, need, rejected.size());
-    if (have == 0) HIPCHK(hipStreamCreateWithFlags(&c->enc_streams[have++], hipStreamNonBlocking));
-    for (int j = have; j < need; ++j) c->enc_streams[j] = c->enc_streams[j % have];     // shared: those stages take turns
+    if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: %zu streams given up\n", rejected.size());
+    if (getenv("RVM_VERBOSE")) fprintf(stderr, "[rvm] frame pipeline: %zu of %d stage streams on queues of their own (%zu streams shared a queue)\n", own.size(), need, rejected.size());
+    if (own.empty()) { hipStream_t s0 = nullptr; HIPCHK(hipStreamCreateWithPriority(&s0, hipStreamNonBlocking, prio)); own.push_back(s0); }
+    for (int j = 0; j < 4; ++j) c->enc_streams[j] = j < need ? own[j % own.size()] : ((size_t)j < own.size() ? own[j] : nullptr);   // shared: those stages take turns
+    if (!seen) {
+        // the caller's streams probed before stay good only if every stream kept then is still in use
+        if (dropped) c->probed_streams.clear();
+        if (c->probed_streams.size() >= 16) c->probed_streams.erase(c->probed_streams.begin());
+        c->probed_streams.push_back(st);
+        ++c->stream_picks;
+    }
     return 0;
 }
 
@@ -2081,7 +2125,7 @@ static int forward_impl(rvm_ctx* c, FrameIO& io, const void* const r_in[4], void
         // decoder phase, on the caller's stream, for the last encoder stage.
         const int NE = c->enc_stages, S = NE + 1, p = c->frame_set % S;      // (% S: the plan before this one may have had more sets)
         auto& L = p ? c->launch_sets[p - 1] : c->launches;
-        if (!c->enc_streams[NE - 1]) { const int rc = pick_stage_streams(c, st, NE); if (rc) return rc; }
+        { const int rc = pick_stage_streams(c, st, NE); if (rc) return rc; }
         if (!c->pipe_sync) {
             // (stream priorities make no difference: encoder streams at the lowest / highest priority measured 211.7 / 209.9 us
             //  per HD frame against 210.0)

@@ -214,3 +214,26 @@ def test_two_shapes_interleaved_through_one_pipelined_module():
     m.pipeline_frames(True)
     _same(want, run())
     _same(want, run())
+
+
+def test_caller_goes_over_to_other_streams():
+    """The caller's stream changes between clips - ordinary torch streams, then a high-priority one, then the default stream
+    again: the stage streams are probed against each new stream (and take its priority; with normal-priority stage streams
+    under a high-priority caller this very sequence never completed), the bits stay the same."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dtype = torch.float16
+    clip = _clip(24, 1080, 1920, dtype)
+    torch.cuda.synchronize()
+    m = _model(dtype)
+    want = _run(m, clip, 0.25, sync_every_frame=True)
+    m.pipeline_frames(True)
+    _same(want, _run(m, clip, 0.25, sync_every_frame=False))
+    main = torch.cuda.current_stream()
+    for s in [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(priority=-1)]:
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            got = _run(m, clip, 0.25, sync_every_frame=False)
+        main.wait_stream(s)
+        _same(want, got)
+    _same(want, _run(m, clip, 0.25, sync_every_frame=False))
