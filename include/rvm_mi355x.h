@@ -178,6 +178,7 @@ int rvm_set_graph_mode(rvm_ctx* ctx, int enabled);
  * rvm_plan / rvm_plan_seq again after changing it (a context keeps plans of both kinds).  Costs one more set of the
  * encoder's buffers per stage in the arena (rvm_memory_bytes) and one more launch per frame in the 16-bit modes.  In graph
  * mode (rvm_set_graph_mode) the decoder phase replays as a HIP graph as well, one per (state pointers, buffer set).
+ * A call that finds the frame before complete (nothing in flight) runs all of its launches on `hip_stream`.
  * The stage streams are chosen against `hip_stream` - on hardware queues of their own, with its priority - at the first
  * pipelined call on it: a call on a stream the context has not seen before synchronises the device twice (~1 ms, at most
  * eight times per context unless the priority changes).

@@ -237,3 +237,37 @@ def test_caller_goes_over_to_other_streams():
         main.wait_stream(s)
         _same(want, got)
     _same(want, _run(m, clip, 0.25, sync_every_frame=False))
+
+
+def test_frames_that_find_the_device_idle_mixed_with_pipelined_ones():
+    """A frame that finds nothing in flight (the caller waited, or was slow) runs on the caller's stream without the
+    cross-stream hand-offs; the next one may be pipelined beside it.  Any mix gives the same bits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import random
+    import time
+    dtype = torch.float16
+    clip = _clip(60, 540, 960, dtype, B=2)
+    torch.cuda.synchronize()
+    m = _model(dtype)
+    want = _run(m, clip, 0.25, sync_every_frame=True)
+    m.pipeline_frames(True)
+    _same(want, _run(m, clip, 0.25, sync_every_frame=True))        # every frame finds the device idle
+    frames = [clip[:, t].contiguous() for t in range(clip.shape[1])]
+    torch.cuda.synchronize()
+    for seed in (1, 2):
+        rng = random.Random(seed)
+        rec = [None] * 4
+        got = []
+        with torch.no_grad():
+            for f in frames:
+                r = rng.random()
+                if r < 0.15:
+                    torch.cuda.synchronize()
+                elif r < 0.4:
+                    time.sleep(rng.uniform(1e-4, 1.5e-3))
+                o = m(f, None, *rec, 0.25)
+                rec = o[2:]
+                got.append([x.clone() for x in o])
+        torch.cuda.synchronize()
+        _same(want, got)
