@@ -132,6 +132,33 @@ def test_raw_c_abi_against_golden_fixture(L):
     _check_golden(g, phas, fgr, states)
 
 
+def test_raw_c_abi_frame_pipeline_against_golden_fixture(L):
+    """rvm_set_frame_pipeline before rvm_plan, frames sent without waiting, the first one's src ordered through
+    rvm_frame_pipeline_src_event (an event recorded on the stream that produced the clip): the golden vectors, and the
+    same bits as the one-stream run."""
+    L.rvm_set_frame_pipeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rvm_frame_pipeline_src_event.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    g, params, clip, ds = _golden()
+    h = _make_ctx(L, params)
+    try:
+        base = _run_clip(L, h, clip.cuda().contiguous(), ds)
+        _ok(L, L.rvm_set_frame_pipeline(h, 1))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            dclip = clip.cuda().contiguous()                 # produced on a side stream; no host synchronisation
+            ev = torch.cuda.Event()
+            ev.record(side)
+        _ok(L, L.rvm_plan(h, 1, clip.shape[2], clip.shape[3], ds))       # (the pipeline applies to plans made from now on)
+        _ok(L, L.rvm_frame_pipeline_src_event(h, ctypes.c_void_p(ev.cuda_event)))
+        phas, fgr, states = _run_clip(L, h, dclip, ds)
+    finally:
+        L.rvm_destroy(h)
+    _check_golden(g, phas, fgr, states)
+    assert torch.equal(phas, base[0]) and torch.equal(fgr, base[1])
+    for a, b in zip(states, base[2]):
+        assert torch.equal(a, b)
+
+
 def test_two_contexts_on_two_host_threads_equal_single_runs(L):
     """Two real contexts on one device, each driven from its own host thread on its own HIP stream (the '8 contexts per
     GPU' alternative to batching): every stream equals its single-context run bit for bit."""
