@@ -413,8 +413,10 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16fast", "fp32", "bf16"],
                     help="fp16: fp16 tensors + fp32-accurate arithmetic inside (parity-gated mode); fp16fast: fp16 storage + fp16 MFMA; "
                          "bf16: bf16 tensors at the boundary, same interior as fp16")
-    ap.add_argument("--mode", default="eager", choices=["graph", "eager"],
-                    help="eager (what a drop-in user gets by default) or HIP-graph replay (model.enable_graph())")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="HIP-graph replay of the state-dependent launches (model.enable_graph(); the default here: with the frame "
+                         "pipeline the host thread is next to the bound, and replay takes it out - 5280-5300 frames/s over five "
+                         "processes against 4150-5140 with eager launches) or eager launches (what a drop-in user gets by default)")
     ap.add_argument("--batch", type=int, default=1, help="streams batched per GPU (BASELINE configs[4]: --gpus 8 --batch 8)")
     ap.add_argument("--chunk", type=int, default=1,
                     help="frames of each stream per step (T of a [B,T,3,H,W] input, convert_video's seq_chunk); the headline is 1")

@@ -19,8 +19,8 @@ timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --batch 8 --ste
 timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --chunk 12 --steps 50 > gpurun_out/final_bench_hd_chunk12.txt 2>&1 || exit 1
 timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --workload 4k --chunk 8 --steps 30 > gpurun_out/final_bench_4k_chunk8.txt 2>&1 || exit 1
 timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --workload hd_resnet50 --steps 100 --dump-kernels gpurun_out/final_kernels_rn.json > gpurun_out/final_bench_rn.txt 2>&1 || exit 1
-timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --mode graph --steps 100 > gpurun_out/final_bench_hd_graph.txt 2>&1 || exit 1
-timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --pipeline off > gpurun_out/final_bench_hd_one_stream.txt 2>&1 || exit 1
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --mode eager > gpurun_out/final_bench_hd_eager.txt 2>&1 || exit 1
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --no-also --pipeline off --mode eager > gpurun_out/final_bench_hd_one_stream.txt 2>&1 || exit 1
 timeout -k 10 300 python -u bench.py --workload 4k --driver-pipeline > gpurun_out/final_bench_driver_4k.txt 2>&1 || exit 1
 timeout -k 10 400 python -u bench.py --dump-kernels gpurun_out/final_kernels_hd.json > gpurun_out/final_bench_hd.txt 2>&1 || exit 1
 for f in gpurun_out/final_bench_*.txt; do echo "$f $(tail -n 1 $f | cut -c80-150)"; done

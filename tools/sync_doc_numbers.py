@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 def L(n): return json.loads(open(os.path.join(ROOT, "profiles", rnd, "bench_%s.json" % n)).read())
 r = lambda x: str(round(x))
-hd, k4, b8, rn, bf, f32, fast, c12, c8, gr = [L(n) for n in ("hd", "4k", "hd_b8", "rn", "hd_bf16", "hd_fp32", "hd_fast", "hd_chunk12", "4k_chunk8", "hd_graph")]
+hd, k4, b8, rn, bf, f32, fast, c12, c8, eg = [L(n) for n in ("hd", "4k", "hd_b8", "rn", "hd_bf16", "hd_fp32", "hd_fast", "hd_chunk12", "4k_chunk8", "hd_eager")]
 on = lambda j: r(j["value"]); off = lambda j: r(j["fps_pipeline_off"]); sy = lambda j: r(j["fps_sync_every_frame"])
 def sub(path, pattern, repl, count=1):
     p = os.path.join(ROOT, path); s = open(p).read()
@@ -17,7 +17,7 @@ def sub(path, pattern, repl, count=1):
     print("%-28s %-40s %s" % (path, pattern[:40], "ok" if n else "NOT FOUND"))
     open(p, "w").write(s2)
 rows = [
-    ("HD ds=0.25, 1 stream (headline, configs[1])", "**%s** (graph mode %s)" % (on(hd), on(gr)), off(hd), sy(hd)),
+    ("HD ds=0.25, 1 stream (headline, configs[1])", "**%s** (eager launches %s)" % (on(hd), on(eg)), off(hd), sy(hd)),
     ("4K ds=0.125, 1 stream (configs[2])", "**%s**" % on(k4), off(k4), sy(k4)),
     ("HD, 8 streams batched (per-GPU share of configs[4])", "**%s**" % on(b8), off(b8), sy(b8)),
     ("HD, resnet50 (configs[3])", "**%s**" % on(rn), off(rn), sy(rn)),
@@ -33,12 +33,12 @@ sub("README.md", r"HD \d+ / \d+, 4K\s+\d+ / \d+, 8 batched HD streams \d+ / \d+,
 sub("INTEGRATION.md", r"HD \d+ →\s+\d+ frames/s, 4K \d+ → \d+, 8 batched streams \d+ → \d+, resnet50 \d+ → \d+",
     "HD %s →\n  %s frames/s, 4K %s → %s, 8 batched streams %s → %s, resnet50 %s → %s" % (off(hd), on(hd), off(k4), on(k4), off(b8), on(b8), off(rn), on(rn)))
 head = """Headline numbers of this build (frames/s, pipeline on / one stream; every `src` ring is larger than the 256 MiB Infinity Cache):
-HD %s / %s (a host sync after every frame %s, with the pipeline on %s; graph mode %s / %s), 4K %s / %s, HD bf16 %s / %s, HD fp32 %s / %s,
-HD pure-fp16 arithmetic %s / %s (host-bound with the pipeline), 8 batched HD streams %s / %s, HD in chunks of 12 frames
+HD %s / %s (a host sync after every frame %s, with the pipeline on %s; eager launches %s / %s), 4K %s / %s, HD bf16 %s / %s, HD fp32 %s / %s,
+HD pure-fp16 arithmetic %s / %s, 8 batched HD streams %s / %s, HD in chunks of 12 frames
 %s / %s, 4K in chunks of 8 %s / %s, resnet50 HD %s / %s. The pipelined HD rate (three encoder stages, stage streams picked
-by probing the hardware queues) lies between 4800 and 5400 from process to process (`tools/pipe_queues.sh`); with two stages 4760-4800.
+by probing the hardware queues) reads 5280-5300 over five processes in graph mode (bench.py's default) and 4150-5400 with eager launches, where the host thread is next to the bound.
 45 launches per mobilenetv3 frame, 352 µs by the in-kernel timeline (round 2: 54 launches, 395 µs).
-""" % (on(hd), off(hd), sy(hd), r(hd["fps_sync_every_frame_pipelined"]), on(gr), off(gr), on(k4), off(k4), on(bf), off(bf), on(f32), off(f32), on(fast), off(fast),
+""" % (on(hd), off(hd), sy(hd), r(hd["fps_sync_every_frame_pipelined"]), on(eg), off(eg), on(k4), off(k4), on(bf), off(bf), on(f32), off(f32), on(fast), off(fast),
        on(b8), off(b8), on(c12), off(c12), on(c8), off(c8), on(rn), off(rn))
 p = os.path.join(ROOT, "profiles", rnd, "README.md"); s = open(p).read()
 a = s.index("Headline numbers of this build")
